@@ -1,0 +1,188 @@
+/*
+ * qcnn.h -- C ABI of the MI355X (gfx950) static-quantised VRCNN inference engine.
+ *
+ * The reference has no FFI layer: its public interface is the C++ class API of
+ * inference/qvrcnn.cuh:25-59 and inference/cnn.cuh:17-100, driven by
+ * inference/kernel.cu:74-116.  This header is the boundary underneath that API:
+ * plain pointers and sizes, no C++ or framework types.  include/qvrcnn.h puts the
+ * reference's classes back on top of it.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative QCNN_E_* code on failure;
+ *     qcnn_last_error() returns a thread-local message for the last failure.
+ *   - "device" pointers are HIP device addresses on the GPU the object was created on.
+ *   - activations in the reference layout NCHW_VECT_C are int8 [C/4][H][W][4];
+ *     conv outputs `u` are float32 NCHW (active config INT8x4_EXT_CONFIG,
+ *     inference/mat.cuh:59-73).
+ *   - an engine is not thread-safe; use one engine per host thread / per GPU
+ *     (the reference's threading model, inference/qvrcnn.cu:6).
+ */
+#ifndef QCNN_H
+#define QCNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QCNN_OK 0
+#define QCNN_E_ARG (-1)      /* bad argument (null pointer, size, layer index ...)      */
+#define QCNN_E_IO (-2)       /* file cannot be opened / short read                      */
+#define QCNN_E_FORMAT (-3)   /* model image malformed (size, mul <= 0, shift range)     */
+#define QCNN_E_HIP (-4)      /* a HIP runtime call failed                               */
+#define QCNN_E_STATE (-5)    /* call order (forward before load ...)                    */
+#define QCNN_E_UNSUPPORTED (-6)
+
+#define QCNN_NUM_LAYERS 6 /* C1, C2_1, C2_2, C3_1, C3_2, C4 (inference/qvrcnn.cu:11-18) */
+
+typedef struct qcnn_engine qcnn_t;
+
+const char *qcnn_last_error(void);
+const char *qcnn_version(void);
+int qcnn_device_count(int *count);
+
+/* ---- network level ------------------------------------------------------------------ */
+
+/* qvrcnn::qvrcnn(gpu_num, batch, channel, height, width), inference/qvrcnn.cu:4-29.
+ * Selects the device, creates one stream and allocates every buffer; forward passes
+ * allocate nothing.  batch and channel must be 1 (FRAME/CHANNEL, inference/mat.cuh:23-24). */
+int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t **out);
+
+/* qvrcnn::~qvrcnn, inference/qvrcnn.cu:331-335. */
+int qcnn_destroy(qcnn_t *e);
+
+/* qvrcnn::load_static_para(filename), inference/qvrcnn.cu:47-63: reads the NCHW_VECT_C
+ * static model file (six layers of int8 weights, int32 biases, blu/mul/shift), packs the
+ * weights into MFMA operand order and uploads them.  May be called again to switch model. */
+int qcnn_load_static(qcnn_t *e, const char *path);
+
+/* Same, from a memory image of the file (60 028 bytes). */
+int qcnn_load_static_mem(qcnn_t *e, const void *image, size_t bytes);
+
+/* qvrcnn::load_data(input) -> InputLayer::load, inference/cnn.cu:439-443: blocking copy of
+ * one Y frame (height*width bytes) from host memory into I1.x. */
+int qcnn_upload(qcnn_t *e, const uint8_t *host_y);
+
+/* Same as qcnn_upload but asynchronous on the engine stream (host_y should be pinned). */
+int qcnn_upload_async(qcnn_t *e, const uint8_t *host_y);
+
+/* qvrcnn::forward_blu(), inference/qvrcnn.cu:168-242, as two fused gfx950 kernels enqueued
+ * on the engine stream (asynchronous; follow with qcnn_sync or qcnn_download). */
+int qcnn_forward_blu(qcnn_t *e);
+
+/* The same pass run layer by layer through the qcnn_op_* kernels below, materialising every
+ * buffer of the reference (x_ppro, u, v, conc) in the reference's layouts: the tap/debug mode
+ * (the role of MEM_DBG / viewmem, inference/cnn.cu:203-248). */
+int qcnn_forward_blu_layered(qcnn_t *e);
+
+/* cudaDeviceSynchronize() of inference/kernel.cu:95, restricted to the engine stream. */
+int qcnn_sync(qcnn_t *e);
+
+/* Device address of I1.x_rec (uint8 [H][W]); inference/kernel.cu:96 reads it. */
+void *qcnn_recon_device_ptr(qcnn_t *e);
+/* Device address of I1.x (uint8 [H][W]); lets a caller keep frames resident in HBM. */
+void *qcnn_input_device_ptr(qcnn_t *e);
+
+/* Points the engine at caller-owned device buffers for the next forward passes (frames
+ * already resident in HBM); NULL restores the engine's own I1.x / I1.x_rec. */
+int qcnn_bind_io(qcnn_t *e, const void *dev_y, void *dev_rec);
+
+/* The D2H copy of inference/kernel.cu:96 (synchronises the stream first). */
+int qcnn_download(qcnn_t *e, uint8_t *host_rec);
+int qcnn_download_async(qcnn_t *e, uint8_t *host_rec);
+
+/* Sum of squared differences between a device frame and a device original (uint8, n bytes),
+ * the integer that vrcnn_data::psnr (inference/yuv_data.cpp:87-97) divides by n. */
+int qcnn_sse_device(qcnn_t *e, const void *dev_a, const void *dev_b, size_t n, uint64_t *sse);
+
+/* Taps after qcnn_forward_blu_layered, copied to host in the reference's layouts. */
+enum {
+    QCNN_TAP_X_PPRO = 0, /* int8  [1][H][W][4]           I1.x_ppro (lanes 1..3 zero)      */
+    QCNN_TAP_U_C1 = 1,   /* float [64][H][W]             C1.u                             */
+    QCNN_TAP_U_C2_1 = 2, /* float [32][H][W]                                              */
+    QCNN_TAP_U_C2_2 = 3, /* float [16][H][W]                                              */
+    QCNN_TAP_U_C3_1 = 4, /* float [16][H][W]                                              */
+    QCNN_TAP_U_C3_2 = 5, /* float [32][H][W]                                              */
+    QCNN_TAP_U_C4 = 6,   /* float [1][H][W]                                               */
+    QCNN_TAP_V_C1 = 7,   /* int8  [16][H][W][4]          C1.v                             */
+    QCNN_TAP_CONC1 = 8,  /* int8  [12][H][W][4]          Conc1.conc                       */
+    QCNN_TAP_CONC2 = 9,  /* int8  [12][H][W][4]          Conc2.conc                       */
+    QCNN_TAP_X_REC = 10, /* uint8 [H][W]                 I1.x_rec                         */
+    /* after qcnn_forward_blu (fused path): the one intermediate it keeps in HBM, converted
+     * back to the reference layout of Conc1.conc */
+    QCNN_TAP_FUSED_CONC1 = 11
+};
+int qcnn_tap_bytes(qcnn_t *e, int tap, size_t *bytes);
+int qcnn_tap(qcnn_t *e, int tap, void *host_out, size_t bytes);
+/* Device address of a layered-mode buffer (the public members C*.u / C*.v / Conc*.conc). */
+void *qcnn_tap_device_ptr(qcnn_t *e, int tap);
+
+/* blu, mul, shift of layer l as loaded (CovLayer::blu/mul/shift, inference/cnn.cuh:49-50). */
+int qcnn_layer_params(qcnn_t *e, int layer, int *blu, int *mul, int *shift);
+/* Device addresses of layer l's weights (file order, int8) and float biases (CovLayer::w/b). */
+void *qcnn_layer_w_device_ptr(qcnn_t *e, int layer);
+void *qcnn_layer_b_device_ptr(qcnn_t *e, int layer);
+
+/* Arithmetic of the fused kernels.  At every load the engine proves from the weights whether the
+ * reference's float32 accumulator pipeline (inference/cnn.cu:148-155, inference/mat.cu:275-291)
+ * is identical to integer arithmetic (all |acc|, |bias| < 2^24) and then uses integer epilogues;
+ * otherwise it replays the float32 pipeline literally.  qcnn_set_exact(e, 1) forces the literal
+ * pipeline from the next load on; qcnn_is_exact reports which one the loaded model uses. */
+int qcnn_set_exact(qcnn_t *e, int on);
+int qcnn_is_exact(qcnn_t *e);
+/* The engine's hipStream_t (as void*), for callers that enqueue their own work behind it. */
+void *qcnn_stream(qcnn_t *e);
+
+/* Average device time, in microseconds, of the two fused kernels over the forward passes
+ * enqueued since the last call with reset != 0 (HIP events on the engine stream; enabled by
+ * qcnn_set_timing(e, 1), off by default because the events cost launch latency). */
+int qcnn_set_timing(qcnn_t *e, int on);
+int qcnn_kernel_times_us(qcnn_t *e, double *k_c1c2_us, double *k_c3c4_us, int *passes, int reset);
+
+/* ---- layer level: stateless kernels on raw device pointers ---------------------------- */
+/* Each enqueues on `stream` (a hipStream_t passed as void*, NULL = default stream) and
+ * returns without synchronising. */
+
+/* InputLayer::ppro / HW2HW_VECT_C_PPRO, inference/cnn.cu:445-468: x_ppro[4i] = x[i]-128,
+ * lanes 1..3 written as 0.  x: uint8[n]; x_ppro: int8[4n]. */
+int qcnn_op_ppro(const void *x, void *x_ppro, size_t n, void *stream);
+
+/* CovLayer::ConvForward_static, inference/cnn.cu:145-160: u = float(conv_int32(x, w)) + b.
+ * x: int8 NCHW_VECT_C [pad4(cin)/4][H][W][4]; w: int8 [cout][pad4(cin)/4][ks][ks][4];
+ * b: float[cout]; u: float [cout][H][W].  ks in {1,3,5}. */
+int qcnn_op_conv_static(const void *x, const void *w, const void *b, void *u, int height, int width, int cin,
+                        int cout, int ks, void *stream);
+
+/* CHW2CHW_VECT_C_QUANT_BLU, inference/mat.cu:262-303 (used by quantize_out_blu,
+ * inference/cnn.cu:195-200, and concat_blu, inference/cnn.cu:375-394): ReLU + clip at blu +
+ * requantise + relayout.  u: float [channels][hw]; out: int8 [channels/4][hw][4]. */
+int qcnn_op_quant_blu(const void *u, void *out, size_t hw, int channels, int blu, int mul, int shift,
+                      void *stream);
+
+/* InputLayer::applyRes_y / applyRes_GPU_y, inference/cnn.cu:507-535. */
+int qcnn_op_apply_res_y(const void *x, void *rec, const void *res, int mul, int shift, size_t n, void *stream);
+
+/* ---- device memory helpers for hosts that do not link HIP ------------------------------ */
+int qcnn_set_device(int gpu);
+int qcnn_dev_alloc(void **dev, size_t bytes);
+int qcnn_dev_free(void *dev);
+int qcnn_dev_h2d(void *dev, const void *host, size_t bytes);
+int qcnn_dev_d2h(void *host, const void *dev, size_t bytes);
+int qcnn_dev_memset(void *dev, int value, size_t bytes);
+int qcnn_dev_sync(void);
+int qcnn_host_alloc_pinned(void **host, size_t bytes);
+int qcnn_host_free_pinned(void *host);
+
+/* ---- offline model conversion (host only) ----------------------------------------------- */
+/* HWCN2NCHW_VECT_C_CPU, inference/mat.cu:97-119: out[n][c/4][h][w][c%4] = in[h][w][c][n]. */
+long qcnn_hwcn2nchw_vect_c(const int8_t *hwcn, int h, int w, int c, int n, int8_t *out);
+/* model_qfp_HWCN2NCHW_VECT_C, inference/qvrcnn.cu:558-585, file to file.  `qp` is substituted
+ * into both printf-style patterns as the reference does. */
+int qcnn_model_qfp_hwcn2nchw_vect_c(const char *filein, const char *fileout, int qp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCNN_H */

@@ -1,0 +1,123 @@
+"""ctypes loader for oracle/libqcnn_oracle.so (the C restatement in oracle/qcnn_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by the qcnn_gpu_amd package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libqcnn_oracle.so")
+COUT = (64, 32, 16, 16, 32, 1)
+
+
+class _Taps(C.Structure):
+    _fields_ = [("x_ppro", C.c_void_p), ("u", C.c_void_p * 6), ("v1", C.c_void_p), ("conc1", C.c_void_p),
+                ("conc2", C.c_void_p)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "qcnn_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libqcnn_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.orc_forward_blu.restype = C.c_int
+        L.orc_forward_blu.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_psnr.restype = C.c_double
+        L.orc_psnr.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_sse.restype = C.c_uint64
+        L.orc_sse.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_requant_one.restype = C.c_int8
+        L.orc_requant_one.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_apply_res_one.restype = C.c_uint8
+        L.orc_apply_res_one.argtypes = [C.c_uint8, C.c_float, C.c_int, C.c_int]
+        L.orc_model_bytes.restype = C.c_long
+        L.orc_model_hwcn_bytes.restype = C.c_long
+        L.orc_model_hwcn2nchw_vect_c.restype = C.c_long
+        L.orc_model_hwcn2nchw_vect_c.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        L.orc_hwcn2nchw_vect_c.restype = C.c_long
+        L.orc_hwcn2nchw_vect_c.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_model_params.restype = C.c_int
+        L.orc_model_params.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        L.orc_conv_static.restype = None
+        L.orc_conv_static.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_void_p]
+        L.orc_quant_blu.restype = None
+        L.orc_quant_blu.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def forward_blu(model_bytes: bytes, y: np.ndarray, want_taps: bool = False):
+    """y uint8 [H][W] -> rec uint8 [H][W] (and the taps, in the reference's layouts)."""
+    L = lib()
+    y = np.ascontiguousarray(y, np.uint8)
+    h, w = y.shape
+    rec = np.empty((h, w), np.uint8)
+    mb = np.frombuffer(model_bytes, np.uint8)
+    taps = None
+    tp = None
+    if want_taps:
+        taps = {
+            "x_ppro": np.empty((1, h, w, 4), np.int8),
+            "u": [np.empty((c, h, w), np.float32) for c in COUT],
+            "v1": np.empty((16, h, w, 4), np.int8),
+            "conc1": np.empty((12, h, w, 4), np.int8),
+            "conc2": np.empty((12, h, w, 4), np.int8),
+        }
+        t = _Taps()
+        t.x_ppro = taps["x_ppro"].ctypes.data
+        for i in range(6):
+            t.u[i] = taps["u"][i].ctypes.data
+        t.v1 = taps["v1"].ctypes.data
+        t.conc1 = taps["conc1"].ctypes.data
+        t.conc2 = taps["conc2"].ctypes.data
+        tp = C.byref(t)
+    rc = L.orc_forward_blu(_p(mb), mb.size, _p(y), h, w, _p(rec), tp)
+    if rc:
+        raise ValueError(f"orc_forward_blu failed: {rc}")
+    return (rec, taps) if want_taps else rec
+
+
+def psnr(data: np.ndarray, ori: np.ndarray) -> float:
+    d = np.ascontiguousarray(data, np.uint8)
+    o = np.ascontiguousarray(ori, np.uint8)
+    return float(lib().orc_psnr(_p(d), _p(o), d.size))
+
+
+def sse(data: np.ndarray, ori: np.ndarray) -> int:
+    d = np.ascontiguousarray(data, np.uint8)
+    o = np.ascontiguousarray(ori, np.uint8)
+    return int(lib().orc_sse(_p(d), _p(o), d.size))
+
+
+def model_hwcn2nchw_vect_c(hwcn: bytes) -> bytes:
+    L = lib()
+    src = np.frombuffer(hwcn, np.uint8)
+    dst = np.empty(L.orc_model_bytes(), np.uint8)
+    n = L.orc_model_hwcn2nchw_vect_c(_p(src), src.size, _p(dst), dst.size)
+    if n < 0:
+        raise ValueError("orc_model_hwcn2nchw_vect_c failed")
+    return dst[:n].tobytes()

@@ -1,0 +1,106 @@
+"""ctypes binding of the C ABI in include/qcnn.h (qcnn_gpu_amd/lib/libqcnn.so).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqcnn.so")
+
+# every symbol include/qcnn.h declares
+SYMBOLS = (
+    "qcnn_last_error", "qcnn_version", "qcnn_device_count", "qcnn_create", "qcnn_destroy", "qcnn_load_static",
+    "qcnn_load_static_mem", "qcnn_upload", "qcnn_upload_async", "qcnn_forward_blu", "qcnn_forward_blu_layered",
+    "qcnn_sync", "qcnn_recon_device_ptr", "qcnn_input_device_ptr", "qcnn_bind_io", "qcnn_download",
+    "qcnn_download_async", "qcnn_sse_device", "qcnn_tap_bytes", "qcnn_tap", "qcnn_tap_device_ptr",
+    "qcnn_layer_params", "qcnn_layer_w_device_ptr", "qcnn_layer_b_device_ptr", "qcnn_set_exact", "qcnn_is_exact",
+    "qcnn_stream", "qcnn_set_timing", "qcnn_kernel_times_us", "qcnn_op_ppro", "qcnn_op_conv_static",
+    "qcnn_op_quant_blu", "qcnn_op_apply_res_y", "qcnn_set_device", "qcnn_dev_alloc", "qcnn_dev_free", "qcnn_dev_h2d",
+    "qcnn_dev_d2h", "qcnn_dev_memset", "qcnn_dev_sync", "qcnn_host_alloc_pinned", "qcnn_host_free_pinned",
+    "qcnn_hwcn2nchw_vect_c", "qcnn_model_qfp_hwcn2nchw_vect_c",
+)
+
+TAP_X_PPRO, TAP_U_C1, TAP_U_C2_1, TAP_U_C2_2, TAP_U_C3_1, TAP_U_C3_2, TAP_U_C4 = range(7)
+TAP_V_C1, TAP_CONC1, TAP_CONC2, TAP_X_REC, TAP_FUSED_CONC1 = 7, 8, 9, 10, 11
+
+
+class QcnnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"qcnn error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads libqcnn.so and declares the signatures.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C qcnn_gpu_amd/csrc` "
+                                "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    L.qcnn_last_error.restype = C.c_char_p
+    L.qcnn_version.restype = C.c_char_p
+    L.qcnn_device_count.argtypes = [C.POINTER(i)]
+    L.qcnn_create.argtypes = [i, i, i, i, i, C.POINTER(vp)]
+    L.qcnn_destroy.argtypes = [vp]
+    L.qcnn_load_static.argtypes = [vp, C.c_char_p]
+    L.qcnn_load_static_mem.argtypes = [vp, vp, sz]
+    L.qcnn_upload.argtypes = [vp, vp]
+    L.qcnn_upload_async.argtypes = [vp, vp]
+    L.qcnn_forward_blu.argtypes = [vp]
+    L.qcnn_forward_blu_layered.argtypes = [vp]
+    L.qcnn_sync.argtypes = [vp]
+    L.qcnn_recon_device_ptr.restype = vp
+    L.qcnn_recon_device_ptr.argtypes = [vp]
+    L.qcnn_input_device_ptr.restype = vp
+    L.qcnn_input_device_ptr.argtypes = [vp]
+    L.qcnn_bind_io.argtypes = [vp, vp, vp]
+    L.qcnn_download.argtypes = [vp, vp]
+    L.qcnn_download_async.argtypes = [vp, vp]
+    L.qcnn_sse_device.argtypes = [vp, vp, vp, sz, C.POINTER(C.c_uint64)]
+    L.qcnn_tap_bytes.argtypes = [vp, i, C.POINTER(sz)]
+    L.qcnn_tap.argtypes = [vp, i, vp, sz]
+    L.qcnn_tap_device_ptr.restype = vp
+    L.qcnn_tap_device_ptr.argtypes = [vp, i]
+    L.qcnn_layer_params.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.qcnn_layer_w_device_ptr.restype = vp
+    L.qcnn_layer_w_device_ptr.argtypes = [vp, i]
+    L.qcnn_layer_b_device_ptr.restype = vp
+    L.qcnn_layer_b_device_ptr.argtypes = [vp, i]
+    L.qcnn_set_exact.argtypes = [vp, i]
+    L.qcnn_is_exact.argtypes = [vp]
+    L.qcnn_stream.restype = vp
+    L.qcnn_stream.argtypes = [vp]
+    L.qcnn_set_timing.argtypes = [vp, i]
+    L.qcnn_kernel_times_us.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i), i]
+    L.qcnn_op_ppro.argtypes = [vp, vp, sz, vp]
+    L.qcnn_op_conv_static.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp]
+    L.qcnn_op_quant_blu.argtypes = [vp, vp, sz, i, i, i, i, vp]
+    L.qcnn_op_apply_res_y.argtypes = [vp, vp, vp, i, i, sz, vp]
+    L.qcnn_set_device.argtypes = [i]
+    L.qcnn_dev_alloc.argtypes = [C.POINTER(vp), sz]
+    L.qcnn_dev_free.argtypes = [vp]
+    L.qcnn_dev_h2d.argtypes = [vp, vp, sz]
+    L.qcnn_dev_d2h.argtypes = [vp, vp, sz]
+    L.qcnn_dev_memset.argtypes = [vp, i, sz]
+    L.qcnn_host_alloc_pinned.argtypes = [C.POINTER(vp), sz]
+    L.qcnn_host_free_pinned.argtypes = [vp]
+    L.qcnn_hwcn2nchw_vect_c.restype = C.c_long
+    L.qcnn_hwcn2nchw_vect_c.argtypes = [vp, i, i, i, i, vp]
+    L.qcnn_model_qfp_hwcn2nchw_vect_c.argtypes = [C.c_char_p, C.c_char_p, i]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise QcnnError(rc, load().qcnn_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,727 @@
+// Host side of the C ABI (include/qcnn.h): device memory, model loading and packing, launches.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qcnn_internal.h"
+
+namespace qcnn {
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(QCNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Layer table of qvrcnn::qvrcnn (inference/qvrcnn.cu:11-18).
+static const int L_KS[6] = {5, 3, 5, 3, 1, 3};
+static const int L_CIN[6] = {1, 64, 64, 48, 48, 48};
+static const int L_COUT[6] = {64, 32, 16, 16, 32, 1};
+static inline int pad4(int c) { return (c + 3) / 4 * 4; }
+static inline int wsize(int l) { return L_KS[l] * L_KS[l] * pad4(L_CIN[l]) * L_COUT[l]; }  // inference/cnn.cu:24
+
+static size_t model_bytes()
+{
+    size_t n = 0;
+    for (int l = 0; l < 6; ++l) n += wsize(l) + 4 * L_COUT[l] + 12;
+    return n;
+}
+
+}  // namespace qcnn
+
+using namespace qcnn;
+
+struct qcnn_engine {
+    int gpu = 0, H = 0, W = 0;
+    size_t HW = 0;
+    hipStream_t stream = nullptr;
+    // I1
+    uint8_t *x = nullptr, *x_rec = nullptr;
+    const uint8_t *bound_y = nullptr;
+    uint8_t *bound_rec = nullptr;
+    // fused path
+    int8_t *conc1_int = nullptr;  // [H][W][48]
+    int8_t *wpack = nullptr;
+    int *bias_i = nullptr;
+    float *bias_f = nullptr;
+    unsigned long long *sse_dev = nullptr;
+    // layered path (allocated on first use)
+    bool layered_ready = false;
+    int8_t *x_ppro = nullptr;
+    float *u[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int8_t *v1 = nullptr, *conc1 = nullptr, *conc2 = nullptr;
+    int8_t *w_file[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // CovLayer::w, file order
+    // model
+    bool loaded = false;
+    bool exact = false;  // true: float-pipeline kernels; false: integer fast path proved safe
+    int force_exact = 0;
+    Requant rq[6];
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // 3 per pass
+    size_t ev_used = 0;
+};
+
+namespace qcnn {
+
+static int ensure_layered(qcnn_engine *e)
+{
+    if (e->layered_ready) return QCNN_OK;
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(hipMalloc(&e->x_ppro, 4 * e->HW));
+    for (int l = 0; l < 6; ++l) HIP_TRY(hipMalloc(&e->u[l], sizeof(float) * L_COUT[l] * e->HW));
+    HIP_TRY(hipMalloc(&e->v1, 64 * e->HW));
+    HIP_TRY(hipMalloc(&e->conc1, 48 * e->HW));
+    HIP_TRY(hipMalloc(&e->conc2, 48 * e->HW));
+    e->layered_ready = true;
+    return QCNN_OK;
+}
+
+// Canonical weight accessor on the file layout w[k][c/4][r][s][c%4] (inference/mat.cu:116).
+struct LayerView {
+    const int8_t *w;
+    const int32_t *b;
+    int ks, cin, cout;
+    int at(int k, int c, int r, int s) const
+    {
+        return w[((((size_t)k * (pad4(cin) / 4) + (c >> 2)) * ks + r) * ks + s) * 4 + (c & 3)];
+    }
+};
+
+// Builds the MFMA A-operand fragments (lane order, 16 bytes per lane) the fused kernels expect.
+static void pack_fragments(const LayerView L[6], std::vector<int8_t> &out)
+{
+    out.assign(PackedOffsets::TOTAL, 0);
+    // C1: 32x32x32, two 32-channel tiles.  Row rho of tile t is channel 32t + chperm(rho), chosen so
+    // that lane (pixel, h) of the accumulator holds channels 16h..16h+15 in registers 0..15.
+    // k-group h covers kernel rows 3h..3h+2: bytes 0..11 = (row, s=0..3) x3, bytes 12..14 = s=4.
+    for (int t = 0; t < 2; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int rho = lane & 31, h = lane >> 5;
+            const int ch = 32 * t + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+            int8_t *dst = &out[PackedOffsets::C1W + (t * 64 + lane) * 16];
+            for (int j = 0; j < 15; ++j) {
+                const int row = 3 * h + (j < 12 ? (j >> 2) : (j - 12));
+                const int s = j < 12 ? (j & 3) : 4;
+                dst[j] = row < 5 ? (int8_t)L[0].at(ch, 0, row, s) : 0;
+            }
+        }
+    // C2_2 (5x5, 64 -> 16): fragment (s, r); row = channel; k-group g byte j = input channel 16g+j.
+    for (int s = 0; s < 5; ++s)
+        for (int r = 0; r < 5; ++r)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int rho = lane & 15, g = lane >> 4;
+                int8_t *dst = &out[PackedOffsets::C2W22 + ((s * 5 + r) * 64 + lane) * 16];
+                for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[2].at(rho, 16 * g + j, r, s);
+            }
+    // C2_1 (3x3, 64 -> 32): fragment (s', r', t); row = channel 16t + rho.
+    for (int s = 0; s < 3; ++s)
+        for (int r = 0; r < 3; ++r)
+            for (int t = 0; t < 2; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, g = lane >> 4;
+                    int8_t *dst = &out[PackedOffsets::C2W21 + ((((s * 3 + r) * 2) + t) * 64 + lane) * 16];
+                    for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[1].at(16 * t + rho, 16 * g + j, r, s);
+                }
+    // C3_1 (3x3, 48 -> 16): the B operand is a conc1 pixel in the internal channel order; k-group
+    // g < 3 byte j = internal position 16g + j; k-group 3 is zero.
+    for (int s = 0; s < 3; ++s)
+        for (int r = 0; r < 3; ++r)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int rho = lane & 15, g = lane >> 4;
+                int8_t *dst = &out[PackedOffsets::C3W31 + ((s * 3 + r) * 64 + lane) * 16];
+                if (g < 3)
+                    for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[3].at(rho, refch_of_pos(16 * g + j), r, s);
+            }
+    // C3_2 (1x1, 48 -> 32): two 16-channel tiles.
+    for (int t = 0; t < 2; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int rho = lane & 15, g = lane >> 4;
+            int8_t *dst = &out[PackedOffsets::C3W32 + (t * 64 + lane) * 16];
+            if (g < 3)
+                for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[4].at(16 * t + rho, refch_of_pos(16 * g + j), 0, 0);
+        }
+    // C4 (3x3, 48 -> 1): fragment s; MFMA row rho < 3 is kernel row r = rho.
+    for (int s = 0; s < 3; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int rho = lane & 15, g = lane >> 4;
+            int8_t *dst = &out[PackedOffsets::C4W + (s * 64 + lane) * 16];
+            if (g < 3 && rho < 3)
+                for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[5].at(0, refch_of_pos(16 * g + j), rho, s);
+        }
+}
+
+// Decides whether the integer fast path reproduces the reference's float32 pipeline for THIS
+// model: with every |acc|, |bias| and |acc + bias| below 2^24 all float operations are exact,
+// and with requant(blu) == 127 the clip-to-127 arm equals requantising min(s, blu).
+static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
+{
+    for (int l = 0; l < 5; ++l) {
+        const int in_max = l == 0 ? 128 : 127;  // C1 input is x-128 in [-128,127]; others are in [0,127]
+        for (int k = 0; k < L[l].cout; ++k) {
+            long long sum = 0;
+            for (int c = 0; c < L[l].cin; ++c)
+                for (int r = 0; r < L[l].ks; ++r)
+                    for (int s = 0; s < L[l].ks; ++s) sum += std::abs(L[l].at(k, c, r, s));
+            const long long b = std::llabs((long long)L[l].b[k]);
+            if (sum * in_max + b >= (1ll << 24)) return false;
+        }
+        const Requant &q = rq[l];
+        if (q.blu < 0 || q.mul <= 0 || q.mul >= (1 << 23)) return false;
+        if ((long long)q.blu + q.bias >= (1ll << 23)) return false;
+        const long long top = ((long long)(q.blu + q.bias) * q.mul) >> q.shift;
+        if (top != 127) return false;
+        if ((long long)(q.blu + q.bias) * q.mul >= (1ll << 31)) return false;
+    }
+    return true;
+}
+
+static int load_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
+{
+    if (bytes < model_bytes())
+        return fail(QCNN_E_FORMAT, "model image is %zu bytes, expected %zu", bytes, model_bytes());
+    HIP_TRY(hipSetDevice(e->gpu));
+    LayerView L[6];
+    std::vector<int32_t> bias_i(161);
+    std::vector<float> bias_f(161);
+    const uint8_t *p = img;
+    for (int l = 0; l < 6; ++l) {
+        L[l].w = reinterpret_cast<const int8_t *>(p);
+        L[l].ks = L_KS[l];
+        L[l].cin = L_CIN[l];
+        L[l].cout = L_COUT[l];
+        p += wsize(l);
+        memcpy(&bias_i[BIAS_OFF[l]], p, 4 * L_COUT[l]);
+        L[l].b = &bias_i[BIAS_OFF[l]];
+        p += 4 * L_COUT[l];
+        int32_t q[3];
+        memcpy(q, p, 12);
+        p += 12;
+        if (q[2] < 1 || q[2] > 31) return fail(QCNN_E_FORMAT, "layer %d: shift %d out of range", l, q[2]);
+        if (l < 5 && q[1] <= 0) return fail(QCNN_E_FORMAT, "layer %d: mul %d must be positive", l, q[1]);
+        e->rq[l] = make_requant(q[0], q[1], q[2]);
+        for (int k = 0; k < L_COUT[l]; ++k) bias_f[BIAS_OFF[l] + k] = (float)bias_i[BIAS_OFF[l] + k];  // cnn.cu:104
+    }
+    std::vector<int8_t> packed;
+    pack_fragments(L, packed);
+    e->exact = e->force_exact ? true : !prove_integer_path(L, e->rq);
+    // make sure no kernel of a previous forward pass still reads the old parameters
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->wpack, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->bias_i, bias_i.data(), 161 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->bias_f, bias_f.data(), 161 * sizeof(float), hipMemcpyHostToDevice));
+    for (int l = 0; l < 6; ++l) HIP_TRY(hipMemcpy(e->w_file[l], L[l].w, wsize(l), hipMemcpyHostToDevice));
+    e->loaded = true;
+    return QCNN_OK;
+}
+
+static FusedArgs fused_args(qcnn_engine *e)
+{
+    FusedArgs a;
+    a.y = e->bound_y ? e->bound_y : e->x;
+    a.rec = e->bound_rec ? e->bound_rec : e->x_rec;
+    a.conc1 = e->conc1_int;
+    a.wpack = e->wpack;
+    a.bias_i = e->bias_i;
+    a.bias_f = e->bias_f;
+    a.H = e->H;
+    a.W = e->W;
+    for (int l = 0; l < 6; ++l) a.rq[l] = e->rq[l];
+    return a;
+}
+
+}  // namespace qcnn
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+const char *qcnn_last_error(void) { return g_err.c_str(); }
+const char *qcnn_version(void) { return "qcnn-gfx950 0.1"; }
+
+int qcnn_device_count(int *count)
+{
+    if (!count) return fail(QCNN_E_ARG, "count is null");
+    HIP_TRY(hipGetDeviceCount(count));
+    return QCNN_OK;
+}
+
+int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t **out)
+{
+    if (!out) return fail(QCNN_E_ARG, "out is null");
+    *out = nullptr;
+    if (batch != 1 || channel != 1)
+        return fail(QCNN_E_UNSUPPORTED, "batch=%d channel=%d: only single Y frames (1,1) are supported", batch, channel);
+    if (height < 1 || width < 1 || (long long)height * width > (1ll << 30))
+        return fail(QCNN_E_ARG, "bad frame size %dx%d", width, height);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (gpu < 0 || gpu >= ndev) return fail(QCNN_E_ARG, "gpu %d out of range (%d devices)", gpu, ndev);
+    HIP_TRY(hipSetDevice(gpu));  // qvrcnn.cu:6
+    qcnn_engine *e = new qcnn_engine;
+    e->gpu = gpu;
+    e->H = height;
+    e->W = width;
+    e->HW = (size_t)height * width;
+    auto bail = [&](int rc) {
+        qcnn_destroy(e);
+        return rc;
+    };
+#define HIP_TRY_E(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return bail(fail(QCNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+    HIP_TRY_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY_E(hipMalloc(&e->x, e->HW));
+    HIP_TRY_E(hipMalloc(&e->x_rec, e->HW));
+    HIP_TRY_E(hipMalloc(&e->conc1_int, 48 * e->HW));
+    HIP_TRY_E(hipMalloc(&e->wpack, PackedOffsets::TOTAL));
+    HIP_TRY_E(hipMalloc(&e->bias_i, 161 * sizeof(int)));
+    HIP_TRY_E(hipMalloc(&e->bias_f, 161 * sizeof(float)));
+    HIP_TRY_E(hipMalloc(&e->sse_dev, sizeof(unsigned long long)));
+    for (int l = 0; l < 6; ++l) HIP_TRY_E(hipMalloc(&e->w_file[l], wsize(l)));
+#undef HIP_TRY_E
+    const char *fx = getenv("QCNN_FORCE_EXACT");
+    e->force_exact = fx && atoi(fx) != 0;
+    *out = e;
+    return QCNN_OK;
+}
+
+int qcnn_destroy(qcnn_t *e)
+{
+    if (!e) return QCNN_OK;
+    (void)hipSetDevice(e->gpu);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    (void)hipFree(e->x);
+    (void)hipFree(e->x_rec);
+    (void)hipFree(e->conc1_int);
+    (void)hipFree(e->wpack);
+    (void)hipFree(e->bias_i);
+    (void)hipFree(e->bias_f);
+    (void)hipFree(e->sse_dev);
+    (void)hipFree(e->x_ppro);
+    for (int l = 0; l < 6; ++l) {
+        (void)hipFree(e->u[l]);
+        (void)hipFree(e->w_file[l]);
+    }
+    (void)hipFree(e->v1);
+    (void)hipFree(e->conc1);
+    (void)hipFree(e->conc2);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return QCNN_OK;
+}
+
+int qcnn_load_static_mem(qcnn_t *e, const void *image, size_t bytes)
+{
+    if (!e || !image) return fail(QCNN_E_ARG, "null argument");
+    return load_image(e, static_cast<const uint8_t *>(image), bytes);
+}
+
+int qcnn_load_static(qcnn_t *e, const char *path)
+{
+    if (!e || !path) return fail(QCNN_E_ARG, "null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(QCNN_E_IO, "cannot open model file %s", path);
+    std::vector<uint8_t> buf(model_bytes());
+    const size_t got = fread(buf.data(), 1, buf.size(), fp);
+    fclose(fp);
+    if (got != buf.size()) return fail(QCNN_E_FORMAT, "%s: short model file (%zu of %zu bytes)", path, got, buf.size());
+    return load_image(e, buf.data(), buf.size());
+}
+
+int qcnn_set_exact(qcnn_t *e, int on)
+{
+    // test hook: force the float-pipeline kernels (takes effect at the next load)
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    e->force_exact = on != 0;
+    return QCNN_OK;
+}
+
+int qcnn_is_exact(qcnn_t *e) { return e ? (e->exact ? 1 : 0) : fail(QCNN_E_ARG, "null engine"); }
+
+int qcnn_upload(qcnn_t *e, const uint8_t *host_y)
+{
+    if (!e || !host_y) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(hipMemcpyAsync(e->x, host_y, e->HW, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // InputLayer::load is a blocking cudaMemcpy (cnn.cu:441)
+    return QCNN_OK;
+}
+
+int qcnn_upload_async(qcnn_t *e, const uint8_t *host_y)
+{
+    if (!e || !host_y) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(hipMemcpyAsync(e->x, host_y, e->HW, hipMemcpyHostToDevice, e->stream));
+    return QCNN_OK;
+}
+
+int qcnn_forward_blu(qcnn_t *e)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
+    HIP_TRY(hipSetDevice(e->gpu));
+    const FusedArgs a = fused_args(e);
+    hipEvent_t *ev = nullptr;
+    if (e->timing) {
+        if (e->ev_used + 3 > e->ev.size()) {
+            const size_t old = e->ev.size();
+            if (old < 3 * 65536) {
+                e->ev.resize(old + 3 * 256);
+                for (size_t i = old; i < e->ev.size(); ++i) HIP_TRY(hipEventCreate(&e->ev[i]));
+            }
+        }
+        if (e->ev_used + 3 <= e->ev.size()) {
+            ev = &e->ev[e->ev_used];
+            e->ev_used += 3;
+        }
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[0], e->stream));
+    HIP_TRY(launch_fused_c1c2(a, e->exact, e->stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], e->stream));
+    HIP_TRY(launch_fused_c3c4(a, e->exact, e->stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[2], e->stream));
+    return QCNN_OK;
+}
+
+int qcnn_forward_blu_layered(qcnn_t *e)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
+    int rc = ensure_layered(e);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->gpu));
+    hipStream_t s = e->stream;
+    const int H = e->H, W = e->W;
+    const size_t HW = e->HW;
+    const uint8_t *y = e->bound_y ? e->bound_y : e->x;
+    uint8_t *rec = e->bound_rec ? e->bound_rec : e->x_rec;
+    // the call sequence of qvrcnn::forward_blu, inference/qvrcnn.cu:168-242
+    HIP_TRY(launch_ppro(y, e->x_ppro, HW, s));
+    HIP_TRY(launch_conv_static(e->x_ppro, e->w_file[0], e->bias_f + BIAS_OFF[0], e->u[0], H, W, 1, 64, 5, s));
+    HIP_TRY(launch_quant_blu(e->u[0], e->v1, HW, 64, e->rq[0], s));
+    HIP_TRY(launch_conv_static(e->v1, e->w_file[1], e->bias_f + BIAS_OFF[1], e->u[1], H, W, 64, 32, 3, s));
+    HIP_TRY(launch_conv_static(e->v1, e->w_file[2], e->bias_f + BIAS_OFF[2], e->u[2], H, W, 64, 16, 5, s));
+    HIP_TRY(launch_quant_blu(e->u[1], e->conc1, HW, 32, e->rq[1], s));
+    HIP_TRY(launch_quant_blu(e->u[2], e->conc1 + 32 * HW, HW, 16, e->rq[2], s));
+    HIP_TRY(launch_conv_static(e->conc1, e->w_file[3], e->bias_f + BIAS_OFF[3], e->u[3], H, W, 48, 16, 3, s));
+    HIP_TRY(launch_conv_static(e->conc1, e->w_file[4], e->bias_f + BIAS_OFF[4], e->u[4], H, W, 48, 32, 1, s));
+    HIP_TRY(launch_quant_blu(e->u[3], e->conc2, HW, 16, e->rq[3], s));
+    HIP_TRY(launch_quant_blu(e->u[4], e->conc2 + 16 * HW, HW, 32, e->rq[4], s));
+    HIP_TRY(launch_conv_static(e->conc2, e->w_file[5], e->bias_f + BIAS_OFF[5], e->u[5], H, W, 48, 1, 3, s));
+    HIP_TRY(launch_apply_res_y(y, rec, e->u[5], e->rq[5].mul, e->rq[5].shift, HW, s));
+    return QCNN_OK;
+}
+
+int qcnn_sync(qcnn_t *e)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QCNN_OK;
+}
+
+void *qcnn_recon_device_ptr(qcnn_t *e) { return e ? e->x_rec : nullptr; }
+void *qcnn_input_device_ptr(qcnn_t *e) { return e ? e->x : nullptr; }
+void *qcnn_stream(qcnn_t *e) { return e ? (void *)e->stream : nullptr; }
+
+int qcnn_bind_io(qcnn_t *e, const void *dev_y, void *dev_rec)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    e->bound_y = static_cast<const uint8_t *>(dev_y);
+    e->bound_rec = static_cast<uint8_t *>(dev_rec);
+    return QCNN_OK;
+}
+
+int qcnn_download_async(qcnn_t *e, uint8_t *host_rec)
+{
+    if (!e || !host_rec) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(hipMemcpyAsync(host_rec, e->bound_rec ? e->bound_rec : e->x_rec, e->HW, hipMemcpyDeviceToHost, e->stream));
+    return QCNN_OK;
+}
+
+int qcnn_download(qcnn_t *e, uint8_t *host_rec)
+{
+    int rc = qcnn_download_async(e, host_rec);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QCNN_OK;
+}
+
+int qcnn_sse_device(qcnn_t *e, const void *dev_a, const void *dev_b, size_t n, uint64_t *sse)
+{
+    if (!e || !dev_a || !dev_b || !sse) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(launch_sse(dev_a, dev_b, n, e->sse_dev, e->stream));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, e->sse_dev, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *sse = h;
+    return QCNN_OK;
+}
+
+static int tap_info(qcnn_t *e, int tap, void **dev, size_t *bytes)
+{
+    const size_t HW = e->HW;
+    switch (tap) {
+    case QCNN_TAP_X_PPRO: *dev = e->x_ppro; *bytes = 4 * HW; return 0;
+    case QCNN_TAP_U_C1: case QCNN_TAP_U_C2_1: case QCNN_TAP_U_C2_2: case QCNN_TAP_U_C3_1: case QCNN_TAP_U_C3_2:
+    case QCNN_TAP_U_C4: {
+        const int l = tap - QCNN_TAP_U_C1;
+        *dev = e->u[l];
+        *bytes = sizeof(float) * L_COUT[l] * HW;
+        return 0;
+    }
+    case QCNN_TAP_V_C1: *dev = e->v1; *bytes = 64 * HW; return 0;
+    case QCNN_TAP_CONC1: *dev = e->conc1; *bytes = 48 * HW; return 0;
+    case QCNN_TAP_CONC2: *dev = e->conc2; *bytes = 48 * HW; return 0;
+    case QCNN_TAP_X_REC: *dev = e->bound_rec ? e->bound_rec : e->x_rec; *bytes = HW; return 0;
+    case QCNN_TAP_FUSED_CONC1: *dev = e->conc1_int; *bytes = 48 * HW; return 0;
+    default: return fail(QCNN_E_ARG, "unknown tap %d", tap);
+    }
+}
+
+int qcnn_tap_bytes(qcnn_t *e, int tap, size_t *bytes)
+{
+    if (!e || !bytes) return fail(QCNN_E_ARG, "null argument");
+    void *dev;
+    return tap_info(e, tap, &dev, bytes);
+}
+
+void *qcnn_tap_device_ptr(qcnn_t *e, int tap)
+{
+    if (!e) return nullptr;
+    if (tap != QCNN_TAP_X_REC && tap != QCNN_TAP_FUSED_CONC1 && ensure_layered(e)) return nullptr;
+    void *dev = nullptr;
+    size_t bytes;
+    if (tap_info(e, tap, &dev, &bytes)) return nullptr;
+    return dev;
+}
+
+int qcnn_tap(qcnn_t *e, int tap, void *host_out, size_t bytes)
+{
+    if (!e || !host_out) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->gpu));
+    if (tap != QCNN_TAP_X_REC && tap != QCNN_TAP_FUSED_CONC1) {
+        int rc = ensure_layered(e);
+        if (rc) return rc;
+    }
+    void *dev = nullptr;
+    size_t need = 0;
+    int rc = tap_info(e, tap, &dev, &need);
+    if (rc) return rc;
+    if (bytes < need) return fail(QCNN_E_ARG, "tap %d needs %zu bytes, buffer has %zu", tap, need, bytes);
+    if (tap == QCNN_TAP_FUSED_CONC1) {
+        // convert the fused path's [H][W][48] image to the layout of Conc1.conc in a scratch buffer
+        int8_t *tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, need));
+        hipError_t he = launch_conc_to_ref(e->conc1_int, tmp, e->H, e->W, e->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(host_out, tmp, need, hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        (void)hipFree(tmp);
+        if (he != hipSuccess) return fail(QCNN_E_HIP, "fused conc1 tap failed: %s", hipGetErrorString(he));
+        return QCNN_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(host_out, dev, need, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QCNN_OK;
+}
+
+int qcnn_layer_params(qcnn_t *e, int layer, int *blu, int *mul, int *shift)
+{
+    if (!e || layer < 0 || layer >= 6) return fail(QCNN_E_ARG, "bad layer %d", layer);
+    if (!e->loaded) return fail(QCNN_E_STATE, "no model loaded");
+    if (blu) *blu = e->rq[layer].blu;
+    if (mul) *mul = e->rq[layer].mul;
+    if (shift) *shift = e->rq[layer].shift;
+    return QCNN_OK;
+}
+
+void *qcnn_layer_w_device_ptr(qcnn_t *e, int layer) { return (e && layer >= 0 && layer < 6) ? e->w_file[layer] : nullptr; }
+void *qcnn_layer_b_device_ptr(qcnn_t *e, int layer)
+{
+    return (e && layer >= 0 && layer < 6) ? (void *)(e->bias_f + BIAS_OFF[layer]) : nullptr;
+}
+
+int qcnn_set_timing(qcnn_t *e, int on)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    e->timing = on != 0;
+    return QCNN_OK;
+}
+
+int qcnn_kernel_times_us(qcnn_t *e, double *k_c1c2_us, double *k_c3c4_us, int *passes, int reset)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double ta = 0, tb = 0;
+    const size_t n = e->ev_used / 3;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev[3 * i], e->ev[3 * i + 1]));
+        ta += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev[3 * i + 1], e->ev[3 * i + 2]));
+        tb += ms;
+    }
+    if (k_c1c2_us) *k_c1c2_us = n ? ta * 1000.0 / n : 0;
+    if (k_c3c4_us) *k_c3c4_us = n ? tb * 1000.0 / n : 0;
+    if (passes) *passes = (int)n;
+    if (reset) e->ev_used = 0;
+    return QCNN_OK;
+}
+
+// ---- layer level ---------------------------------------------------------------------------
+int qcnn_op_ppro(const void *x, void *x_ppro, size_t n, void *stream)
+{
+    if (!x || !x_ppro) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(launch_ppro(x, x_ppro, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_conv_static(const void *x, const void *w, const void *b, void *u, int height, int width, int cin,
+                        int cout, int ks, void *stream)
+{
+    if (!x || !w || !b || !u) return fail(QCNN_E_ARG, "null argument");
+    if (height < 1 || width < 1 || cin < 1 || cout < 1) return fail(QCNN_E_ARG, "bad conv shape");
+    if (ks != 1 && ks != 3 && ks != 5) return fail(QCNN_E_UNSUPPORTED, "ksize %d (1, 3 or 5)", ks);
+    HIP_TRY(launch_conv_static(x, w, b, u, height, width, cin, cout, ks, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_quant_blu(const void *u, void *out, size_t hw, int channels, int blu, int mul, int shift, void *stream)
+{
+    if (!u || !out) return fail(QCNN_E_ARG, "null argument");
+    if (mul <= 0 || shift < 1 || shift > 31 || channels < 1) return fail(QCNN_E_ARG, "bad requant parameters");
+    HIP_TRY(launch_quant_blu(u, out, hw, channels, make_requant(blu, mul, shift), (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_apply_res_y(const void *x, void *rec, const void *res, int mul, int shift, size_t n, void *stream)
+{
+    if (!x || !rec || !res) return fail(QCNN_E_ARG, "null argument");
+    if (shift < 1 || shift > 31) return fail(QCNN_E_ARG, "bad shift %d", shift);
+    HIP_TRY(launch_apply_res_y(x, rec, res, mul, shift, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+// ---- device memory helpers ---------------------------------------------------------------------
+int qcnn_set_device(int gpu)
+{
+    HIP_TRY(hipSetDevice(gpu));
+    return QCNN_OK;
+}
+int qcnn_dev_alloc(void **dev, size_t bytes)
+{
+    if (!dev) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipMalloc(dev, bytes ? bytes : 1));
+    return QCNN_OK;
+}
+int qcnn_dev_free(void *dev)
+{
+    HIP_TRY(hipFree(dev));
+    return QCNN_OK;
+}
+int qcnn_dev_h2d(void *dev, const void *host, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    return QCNN_OK;
+}
+int qcnn_dev_d2h(void *host, const void *dev, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return QCNN_OK;
+}
+int qcnn_dev_memset(void *dev, int value, size_t bytes)
+{
+    HIP_TRY(hipMemset(dev, value, bytes));
+    return QCNN_OK;
+}
+int qcnn_dev_sync(void)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    return QCNN_OK;
+}
+int qcnn_host_alloc_pinned(void **host, size_t bytes)
+{
+    if (!host) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault));
+    return QCNN_OK;
+}
+int qcnn_host_free_pinned(void *host)
+{
+    HIP_TRY(hipHostFree(host));
+    return QCNN_OK;
+}
+
+// ---- offline model conversion --------------------------------------------------------------------
+long qcnn_hwcn2nchw_vect_c(const int8_t *hwcn, int h, int w, int c, int n, int8_t *out)
+{
+    if (!hwcn || !out || h < 1 || w < 1 || c < 1 || n < 1) return fail(QCNN_E_ARG, "bad argument");
+    const int c4 = (c + 3) / 4;
+    const long total = (long)n * c4 * h * w * 4;
+    memset(out, 0, (size_t)total);
+    for (int in = 0; in < n; ++in)
+        for (int ic = 0; ic < c; ++ic)
+            for (int ih = 0; ih < h; ++ih)
+                for (int iw = 0; iw < w; ++iw)
+                    out[((((long)in * c4 + (ic >> 2)) * h + ih) * w + iw) * 4 + (ic & 3)] =
+                        hwcn[(((long)ih * w + iw) * c + ic) * n + in];
+    return total;
+}
+
+int qcnn_model_qfp_hwcn2nchw_vect_c(const char *filein, const char *fileout, int qp)
+{
+    if (!filein || !fileout) return fail(QCNN_E_ARG, "null argument");
+    char fn_in[512], fn_out[512];
+    snprintf(fn_in, sizeof fn_in, filein, qp);
+    snprintf(fn_out, sizeof fn_out, fileout, qp);
+    FILE *fi = fopen(fn_in, "rb");
+    if (!fi) return fail(QCNN_E_IO, "failed to open file %s", fn_in);
+    FILE *fo = fopen(fn_out, "wb");
+    if (!fo) {
+        fclose(fi);
+        return fail(QCNN_E_IO, "failed to open file %s", fn_out);
+    }
+    int rc = QCNN_OK;
+    for (int l = 0; l < 6 && rc == QCNN_OK; ++l) {
+        const int ks = L_KS[l], c = L_CIN[l], n = L_COUT[l];
+        std::vector<int8_t> win((size_t)ks * ks * c * n), wout((size_t)wsize(l));
+        std::vector<int32_t> tail(n + 3);
+        if (fread(win.data(), 1, win.size(), fi) != win.size() ||
+            fread(tail.data(), 4, tail.size(), fi) != tail.size()) {
+            rc = fail(QCNN_E_FORMAT, "%s: short HWCN model file at layer %d", fn_in, l);
+            break;
+        }
+        qcnn_hwcn2nchw_vect_c(win.data(), ks, ks, c, n, wout.data());
+        if (fwrite(wout.data(), 1, wout.size(), fo) != wout.size() ||
+            fwrite(tail.data(), 4, tail.size(), fo) != tail.size())
+            rc = fail(QCNN_E_IO, "%s: write failed", fn_out);
+    }
+    fclose(fi);
+    fclose(fo);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// Internal declarations shared by the engine (host) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "qcnn.h"
+
+namespace qcnn {
+
+// Requantiser constants of one conv layer, derived once from (blu, mul, shift) the way
+// CHW2CHW_VECT_C_QUANT_BLU does (inference/mat.cu:268): bias = (1 << (shift-1)) / mul.
+struct Requant {
+    int blu;
+    int mul;
+    int shift;
+    int bias;   // (1 << (shift-1)) / mul
+    int cmul;   // bias * mul  (so that (v + bias) * mul == v * mul + cmul, mod 2^32)
+    float bluf; // (float)blu, the value the reference's float compare sees
+};
+
+// ---- fused kernel geometry -------------------------------------------------------------
+// Kernel A: Y -> C1 -> (C2_1 || C2_2) -> conc1 in HBM, one 16 x 32 output tile per workgroup.
+namespace ka {
+constexpr int TH = 16, TW = 32;
+constexpr int C1R = TH + 4, C1C = TW + 4;  // C1 output region held in LDS (halo 2)
+constexpr int YR = TH + 9, YC = TW + 8;    // plain Y tile rows/cols (halo 4, +1 row of slack)
+constexpr int Y16R = TH + 7;               // rows of the 16-byte-per-pixel im2col image
+constexpr int SC1_BYTES = C1R * C1C * 64;
+constexpr int SY16_BYTES = Y16R * C1C * 16;
+constexpr int SY_BYTES = (YR * YC + 15) / 16 * 16;
+constexpr int LDS_BYTES = SC1_BYTES + SY16_BYTES + SY_BYTES;
+}  // namespace ka
+
+// Kernel B: conc1 -> (C3_1 || C3_2) -> C4 -> residual add, one 18 x 30 output tile per workgroup.
+namespace kb {
+constexpr int TH = 18, TW = 30;
+constexpr int C3R = TH + 2, C3C = 32;   // C3 output region held in LDS (halo 1)
+constexpr int INR = TH + 4, INC = 34;   // conc1 input region (halo 2)
+constexpr int PX = 48;                  // bytes per pixel of conc1 / conc2 images
+constexpr int SIN_BYTES = INR * INC * PX;
+constexpr int SC3_BYTES = C3R * C3C * PX + 256;  // + slack: edge lanes read 2 pixels past a row
+constexpr int LDS_BYTES = SIN_BYTES + SC3_BYTES;
+}  // namespace kb
+
+// Offsets (bytes) of the packed MFMA A-operand fragments inside one device buffer.
+// One fragment = 64 lanes x 16 bytes = 1 KiB, stored in lane order.
+struct PackedOffsets {
+    static constexpr int C1W = 0;                       // 2 fragments (32x32x32)
+    static constexpr int C2W22 = C1W + 2 * 1024;        // 25 fragments [s][r]
+    static constexpr int C2W21 = C2W22 + 25 * 1024;     // 18 fragments [s'][r'][t]
+    static constexpr int C3W31 = C2W21 + 18 * 1024;     // 9 fragments [s][r]
+    static constexpr int C3W32 = C3W31 + 9 * 1024;      // 2 fragments [t]
+    static constexpr int C4W = C3W32 + 2 * 1024;        // 3 fragments [s]
+    static constexpr int TOTAL = C4W + 3 * 1024;
+};
+
+// Arguments of the fused kernels (passed by value).
+struct FusedArgs {
+    const uint8_t *y;        // I1.x       uint8 [H][W]
+    uint8_t *rec;            // I1.x_rec   uint8 [H][W]
+    int8_t *conc1;           // [H][W][48] int8, internal channel order (see pack_position())
+    const int8_t *wpack;     // packed fragments, PackedOffsets
+    const int *bias_i;       // int32 biases, 6 layers concatenated: 64,32,16,16,32,1 (=161)
+    const float *bias_f;     // same, converted to float as CovLayer::load_static_para does
+    int H, W;
+    Requant rq[QCNN_NUM_LAYERS];
+};
+
+// Offsets of each layer's biases inside bias_i / bias_f.
+constexpr int BIAS_OFF[QCNN_NUM_LAYERS] = {0, 64, 96, 112, 128, 160};
+
+// Internal channel order of the 48-channel images conc1 / conc2: the byte at position `pos` of a
+// pixel holds reference channel refch(pos).  It makes every lane of a 16x16 MFMA output tile own
+// 12 consecutive bytes.  pos = 12*g + 4*t + i  <->  channel 16*t + 4*g + i.
+__host__ __device__ inline int refch_of_pos(int pos)
+{
+    const int g = pos / 12, t = (pos % 12) / 4, i = pos % 4;
+    return 16 * t + 4 * g + i;
+}
+__host__ __device__ inline int pos_of_refch(int ch)
+{
+    const int t = ch / 16, g = (ch % 16) / 4, i = ch % 4;
+    return 12 * g + 4 * t + i;
+}
+
+// ---- kernel launchers (defined in the .hip files) ----------------------------------------
+hipError_t launch_ppro(const void *x, void *x_ppro, size_t n, hipStream_t s);
+hipError_t launch_conv_static(const void *x, const void *w, const void *b, void *u, int H, int W, int cin,
+                              int cout, int ks, hipStream_t s);
+hipError_t launch_quant_blu(const void *u, void *out, size_t hw, int channels, const Requant &rq, hipStream_t s);
+hipError_t launch_apply_res_y(const void *x, void *rec, const void *res, int mul, int shift, size_t n,
+                              hipStream_t s);
+hipError_t launch_sse(const void *a, const void *b, size_t n, unsigned long long *dev_sum, hipStream_t s);
+hipError_t launch_conc_to_ref(const void *conc_internal, void *conc_ref, int H, int W, hipStream_t s);
+hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s);
+hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s);
+
+Requant make_requant(int blu, int mul, int shift);
+
+}  // namespace qcnn

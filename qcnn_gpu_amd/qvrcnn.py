@@ -1,0 +1,142 @@
+"""Python view of the reference's `class qvrcnn` (inference/qvrcnn.cuh:25-59) over the C ABI.
+
+Method names and call order follow the reference driver (inference/kernel.cu:86-96):
+    net = qvrcnn(gpu_num, batch, channel, height, width)
+    net.load_static_para(filename)
+    net.load_data(frame)          # host uint8 [H][W]
+    net.forward_blu()
+    net.synchronize()             # cudaDeviceSynchronize() in the reference
+    rec = net.download()          # the cudaMemcpy from I1.x_rec
+The C++ twin of this class (include/qvrcnn.h) is what a C++ caller of the reference would use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .formats import LAYERS
+
+_TAP_SHAPES = {
+    capi.TAP_X_PPRO: (np.int8, lambda h, w: (1, h, w, 4)),
+    capi.TAP_U_C1: (np.float32, lambda h, w: (64, h, w)),
+    capi.TAP_U_C2_1: (np.float32, lambda h, w: (32, h, w)),
+    capi.TAP_U_C2_2: (np.float32, lambda h, w: (16, h, w)),
+    capi.TAP_U_C3_1: (np.float32, lambda h, w: (16, h, w)),
+    capi.TAP_U_C3_2: (np.float32, lambda h, w: (32, h, w)),
+    capi.TAP_U_C4: (np.float32, lambda h, w: (1, h, w)),
+    capi.TAP_V_C1: (np.int8, lambda h, w: (16, h, w, 4)),
+    capi.TAP_CONC1: (np.int8, lambda h, w: (12, h, w, 4)),
+    capi.TAP_CONC2: (np.int8, lambda h, w: (12, h, w, 4)),
+    capi.TAP_X_REC: (np.uint8, lambda h, w: (h, w)),
+    capi.TAP_FUSED_CONC1: (np.int8, lambda h, w: (12, h, w, 4)),
+}
+
+
+class qvrcnn:
+    def __init__(self, gpu_num: int, batch: int, channel: int, height: int, width: int):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        capi.check(self._lib.qcnn_create(gpu_num, batch, channel, height, width, C.byref(self._h)))
+        self.batch, self.channel, self.height, self.width = batch, channel, height, width
+
+    # -- reference API ---------------------------------------------------------------------
+    def load_static_para(self, filename) -> int:
+        if isinstance(filename, (bytes, bytearray, memoryview)) and len(filename) > 4096:
+            buf = bytes(filename)
+            capi.check(self._lib.qcnn_load_static_mem(self._h, buf, len(buf)))
+        else:
+            name = filename if isinstance(filename, bytes) else str(filename).encode()
+            capi.check(self._lib.qcnn_load_static(self._h, name))
+        return 0
+
+    def load_data(self, frame: np.ndarray) -> int:
+        frame = np.ascontiguousarray(frame, np.uint8)
+        if frame.size != self.height * self.width:
+            raise ValueError("frame must hold channel*height*width bytes")
+        capi.check(self._lib.qcnn_upload(self._h, frame.ctypes.data_as(C.c_void_p)))
+        return 0
+
+    def forward_blu(self) -> int:
+        capi.check(self._lib.qcnn_forward_blu(self._h))
+        return 0
+
+    # -- additions ---------------------------------------------------------------------------
+    def forward_blu_layered(self) -> int:
+        capi.check(self._lib.qcnn_forward_blu_layered(self._h))
+        return 0
+
+    def synchronize(self) -> None:
+        capi.check(self._lib.qcnn_sync(self._h))
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.height, self.width), np.uint8)
+        capi.check(self._lib.qcnn_download(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def tap(self, which: int) -> np.ndarray:
+        dt, shp = _TAP_SHAPES[which]
+        out = np.empty(shp(self.height, self.width), dt)
+        capi.check(self._lib.qcnn_tap(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def layer_params(self, layer: int):
+        b, m, s = C.c_int(), C.c_int(), C.c_int()
+        capi.check(self._lib.qcnn_layer_params(self._h, layer, C.byref(b), C.byref(m), C.byref(s)))
+        return b.value, m.value, s.value
+
+    def set_exact(self, on: bool) -> None:
+        capi.check(self._lib.qcnn_set_exact(self._h, int(on)))
+
+    @property
+    def is_exact(self) -> bool:
+        return bool(capi.check(self._lib.qcnn_is_exact(self._h)))
+
+    def bind_io(self, dev_y: int, dev_rec: int) -> None:
+        capi.check(self._lib.qcnn_bind_io(self._h, C.c_void_p(dev_y), C.c_void_p(dev_rec)))
+
+    def set_timing(self, on: bool) -> None:
+        capi.check(self._lib.qcnn_set_timing(self._h, int(on)))
+
+    def kernel_times_us(self, reset: bool = True):
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        capi.check(self._lib.qcnn_kernel_times_us(self._h, C.byref(a), C.byref(b), C.byref(n), int(reset)))
+        return a.value, b.value, n.value
+
+    def sse_device(self, dev_a: int, dev_b: int, n: int) -> int:
+        s = C.c_uint64()
+        capi.check(self._lib.qcnn_sse_device(self._h, C.c_void_p(dev_a), C.c_void_p(dev_b), n, C.byref(s)))
+        return s.value
+
+    @property
+    def x_rec_ptr(self) -> int:
+        return self._lib.qcnn_recon_device_ptr(self._h)
+
+    @property
+    def x_ptr(self) -> int:
+        return self._lib.qcnn_input_device_ptr(self._h)
+
+    @property
+    def stream(self) -> int:
+        return self._lib.qcnn_stream(self._h)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.qcnn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+__all__ = ["qvrcnn", "LAYERS"]

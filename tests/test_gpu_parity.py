@@ -1,0 +1,238 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle -- bit-exact.
+
+Tolerance: none.  Every comparison below is np.array_equal on bytes (uint8 / int8) or on float32
+bit patterns of integer-valued accumulators.
+"""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from qcnn_gpu_amd import capi, formats, synth
+from qcnn_gpu_amd.qvrcnn import qvrcnn
+
+pytestmark = pytest.mark.gpu
+
+U_TAPS = [capi.TAP_U_C1, capi.TAP_U_C2_1, capi.TAP_U_C2_2, capi.TAP_U_C3_1, capi.TAP_U_C3_2, capi.TAP_U_C4]
+
+
+def _frame(h, w, qp, seed=1):
+    return synth.synth_frames(h, w, qp, seed=seed)[1][0]
+
+
+def _check_layered(net, mb, y):
+    rec_o, taps_o = c_oracle.forward_blu(mb, y, True)
+    net.load_data(y)
+    net.forward_blu_layered()
+    net.synchronize()
+    assert np.array_equal(net.tap(capi.TAP_X_PPRO), taps_o["x_ppro"])
+    for l, t in enumerate(U_TAPS):
+        got = net.tap(t)
+        assert np.array_equal(got.view(np.uint32), taps_o["u"][l].view(np.uint32)), f"u[{l}]"
+    assert np.array_equal(net.tap(capi.TAP_V_C1), taps_o["v1"])
+    assert np.array_equal(net.tap(capi.TAP_CONC1), taps_o["conc1"])
+    assert np.array_equal(net.tap(capi.TAP_CONC2), taps_o["conc2"])
+    assert np.array_equal(net.download(), rec_o)
+    return rec_o, taps_o
+
+
+def _check_fused(net, y, rec_o, conc1_o):
+    net.load_data(y)
+    net.forward_blu()
+    net.synchronize()
+    conc1 = net.tap(capi.TAP_FUSED_CONC1)
+    bad = np.argwhere(conc1 != conc1_o)
+    assert bad.size == 0, f"fused conc1 differs at {bad[:5].tolist()} ({len(bad)} bytes)"
+    rec = net.download()
+    bad = np.argwhere(rec != rec_o)
+    assert bad.size == 0, f"fused x_rec differs at {bad[:5].tolist()} ({len(bad)} pixels)"
+
+
+def test_mfma_device_present():
+    n = C.c_int()
+    capi.check(capi.load().qcnn_device_count(C.byref(n)))
+    assert n.value >= 1
+
+
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_golden_case_layered_and_fused(qp, golden_dir):
+    case = np.load(f"{golden_dir}/synth_case_qp{qp}.npz")
+    with open(f"{golden_dir}/synth_model_qp{qp}.data", "rb") as f:
+        mb = f.read()
+    y = case["anchor"]
+    with qvrcnn(0, 1, 1, *y.shape) as net:
+        net.load_static_para(f"{golden_dir}/synth_model_qp{qp}.data")
+        assert net.layer_params(0) == synth.QUANT_TRIPLES[qp][0]
+        rec_o, taps_o = _check_layered(net, mb, y)
+        assert np.array_equal(rec_o, case["rec"])
+        crcs = dict(zip(case["crc_names"].tolist(), case["crc_values"].tolist()))
+        assert zlib.crc32(net.tap(capi.TAP_CONC2).tobytes()) == crcs["conc2"]
+        assert not net.is_exact                       # realistic weights: integer epilogues proved safe
+        _check_fused(net, y, case["rec"], case["conc1"])
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 7), (16, 32), (18, 30), (17, 31), (19, 33), (36, 60), (37, 61),
+                                   (67, 131), (240, 416)])
+def test_fused_matches_oracle_on_ragged_sizes(shape):
+    qp = 37
+    m = synth.synth_model(qp)
+    mb = m.to_nchw_vect_c_bytes()
+    y = _frame(shape[0], shape[1], qp, seed=shape[0] * 7 + shape[1])
+    rec_o, taps_o = c_oracle.forward_blu(mb, y, True)
+    with qvrcnn(0, 1, 1, *shape) as net:
+        net.load_static_para(mb)
+        _check_fused(net, y, rec_o, taps_o["conc1"])
+        if shape[0] * shape[1] <= 40 * 60:
+            _check_layered(net, mb, y)
+
+
+@pytest.mark.parametrize("qp", [22, 27, 32])
+def test_fused_float_pipeline_variant(qp):
+    """EXACT kernels (literal float32 accumulator pipeline) give the same bytes as the integer ones."""
+    m = synth.synth_model(qp)
+    mb = m.to_nchw_vect_c_bytes()
+    y = _frame(45, 77, qp)
+    rec_o, taps_o = c_oracle.forward_blu(mb, y, True)
+    with qvrcnn(0, 1, 1, 45, 77) as net:
+        net.set_exact(True)
+        net.load_static_para(mb)
+        assert net.is_exact
+        _check_fused(net, y, rec_o, taps_o["conc1"])
+        net.set_exact(False)
+        net.load_static_para(mb)
+        assert not net.is_exact
+        _check_fused(net, y, rec_o, taps_o["conc1"])
+
+
+@pytest.mark.parametrize("kind", ["maxmag", "identity"])
+def test_adversarial_models(kind):
+    m = synth.adversarial_model(kind)
+    mb = m.to_nchw_vect_c_bytes()
+    frames = [np.zeros((21, 35), np.uint8), np.full((21, 35), 255, np.uint8), _frame(21, 35, 37)]
+    with qvrcnn(0, 1, 1, 21, 35) as net:
+        net.load_static_para(mb)
+        if kind == "maxmag":
+            assert net.is_exact               # accumulators can pass 2^24: float pipeline is selected
+        for y in frames:
+            rec_o, taps_o = _check_layered(net, mb, y)
+            _check_fused(net, y, rec_o, taps_o["conc1"])
+
+
+def test_all_four_qp_models_back_to_back():
+    """configs[2]: the four QP models loaded one after another into one engine."""
+    h, w = 72, 100
+    with qvrcnn(0, 1, 1, h, w) as net:
+        for qp in (22, 27, 32, 37, 22):
+            mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+            y = _frame(h, w, qp)
+            rec_o, taps_o = c_oracle.forward_blu(mb, y, True)
+            net.load_static_para(mb)
+            _check_fused(net, y, rec_o, taps_o["conc1"])
+
+
+def test_full_hd_frame_bit_exact():
+    """configs[1]: one 1920x1080 Y frame, QP37, memcmp-equal with the oracle, + PSNR equality."""
+    qp, h, w = 37, 1080, 1920
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    ori, anc = synth.synth_frames(h, w, qp)
+    rec_o, taps_o = c_oracle.forward_blu(mb, anc[0], True)
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        _check_fused(net, anc[0], rec_o, taps_o["conc1"])
+        # idempotence of the engine state: a second pass gives the same bytes
+        net.forward_blu()
+        net.synchronize()
+        rec = net.download()
+        assert np.array_equal(rec, rec_o)
+        # PSNR "to the last printed decimal": identical integer SSE => identical double
+        lib = capi.load()
+        d_ori = C.c_void_p()
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_ori), h * w))
+        capi.check(lib.qcnn_dev_h2d(d_ori, ori[0].ctypes.data, h * w))
+        sse = net.sse_device(net.x_rec_ptr, d_ori.value, h * w)
+        capi.check(lib.qcnn_dev_free(d_ori))
+        assert sse == c_oracle.sse(rec_o, ori[0])
+        assert formats.psnr_from_sse(sse, h * w) == c_oracle.psnr(rec_o, ori[0])
+        # layered mode at full size agrees too
+        net.forward_blu_layered()
+        net.synchronize()
+        assert np.array_equal(net.download(), rec_o)
+        assert np.array_equal(net.tap(capi.TAP_CONC2), taps_o["conc2"])
+
+
+def test_tile_independence_property():
+    """Size-independent property: the output at a pixel depends only on its 13x13 neighbourhood, so a
+    crop taken 6 pixels inside a larger frame equals the same region of the full result."""
+    qp, h, w = 32, 200, 333
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    y = _frame(h, w, qp)
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        net.load_data(y)
+        net.forward_blu()
+        full = net.download()
+    y0, x0, ch, cw = 37, 51, 90, 140
+    crop = np.ascontiguousarray(y[y0:y0 + ch, x0:x0 + cw])
+    with qvrcnn(0, 1, 1, ch, cw) as net:
+        net.load_static_para(mb)
+        net.load_data(crop)
+        net.forward_blu()
+        part = net.download()
+    assert np.array_equal(part[6:-6, 6:-6], full[y0 + 6:y0 + ch - 6, x0 + 6:x0 + cw - 6])
+
+
+def test_layer_ops_on_raw_pointers():
+    """qcnn_op_* : the reference's layer API on caller-owned device buffers."""
+    lib = capi.load()
+    h, w, cin, cout, ks = 23, 37, 48, 16, 3
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 128, (cin // 4, h, w, 4), dtype=np.int8)
+    wt = rng.integers(-128, 128, (cout, cin // 4, ks, ks, 4), dtype=np.int8)
+    b = rng.integers(-3000, 3000, cout).astype(np.int32)
+    u_ref = np.empty((cout, h, w), np.float32)
+    c_oracle.lib().orc_conv_static(x.ctypes.data, cin, h, w, wt.ctypes.data, b.ctypes.data, cout, ks,
+                                   u_ref.ctypes.data)
+    v_ref = np.empty((cout // 4, h, w, 4), np.int8)
+    c_oracle.lib().orc_quant_blu(u_ref.ctypes.data, v_ref.ctypes.data, h * w, cout, 7426, 281, 14)
+
+    def dev(a):
+        p = C.c_void_p()
+        capi.check(lib.qcnn_dev_alloc(C.byref(p), a.nbytes))
+        capi.check(lib.qcnn_dev_h2d(p, a.ctypes.data, a.nbytes))
+        return p
+
+    bf = b.astype(np.float32)
+    dx, dw, db = dev(x), dev(wt), dev(bf)
+    du, dv = dev(np.zeros_like(u_ref)), dev(np.zeros_like(v_ref))
+    capi.check(lib.qcnn_op_conv_static(dx, dw, db, du, h, w, cin, cout, ks, None))
+    capi.check(lib.qcnn_op_quant_blu(du, dv, h * w, cout, 7426, 281, 14, None))
+    capi.check(lib.qcnn_dev_sync())
+    u = np.empty_like(u_ref)
+    v = np.empty_like(v_ref)
+    capi.check(lib.qcnn_dev_d2h(u.ctypes.data, du, u.nbytes))
+    capi.check(lib.qcnn_dev_d2h(v.ctypes.data, dv, v.nbytes))
+    assert np.array_equal(u, u_ref) and np.array_equal(v, v_ref)
+    for p in (dx, dw, db, du, dv):
+        capi.check(lib.qcnn_dev_free(p))
+    assert lib.qcnn_op_conv_static(dx, dw, db, du, h, w, cin, cout, 7, None) == -6     # unsupported ksize
+
+
+def test_error_reporting():
+    lib = capi.load()
+    with qvrcnn(0, 1, 1, 8, 8) as net:
+        with pytest.raises(capi.QcnnError) as ei:
+            net.forward_blu()                             # no model loaded
+        assert ei.value.code == -5
+        with pytest.raises(capi.QcnnError) as ei:
+            net.load_static_para("/nonexistent/model.data")
+        assert ei.value.code == -2 and "cannot open model file" in str(ei.value)
+        bad = bytearray(synth.synth_model(37).to_nchw_vect_c_bytes())
+        bad[-4:] = (0).to_bytes(4, "little")              # C4 shift = 0
+        with pytest.raises(capi.QcnnError) as ei:
+            net.load_static_para(bytes(bad))
+        assert ei.value.code == -3
+    h = C.c_void_p()
+    assert lib.qcnn_create(0, 2, 1, 8, 8, C.byref(h)) == -6      # batch != 1
+    assert lib.qcnn_create(99, 1, 1, 8, 8, C.byref(h)) == -1     # no such device
