@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path qvrcnn::forward_blu (inference/qvrcnn.cu:168-242) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of forward_blu over one batch of synthetic Y frames that are already resident
+in HBM (default: 16 frames of 1920x1080, QP37 model: BASELINE.json configs[1]).  With N > 1 the
+script is launched once per GPU by torch.distributed.run; frames are sharded across ranks with no
+data-path collective (weak scaling), and the only communication is the barrier / max-reduction that
+brackets the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from qcnn_gpu_amd import capi, quant_tables, synth  # noqa: E402
+from qcnn_gpu_amd.formats import LAYERS, MACS_PER_PIXEL  # noqa: E402
+from qcnn_gpu_amd.qvrcnn import qvrcnn  # noqa: E402
+
+PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA peak of MI355X: 2x the ~2.5 PFLOP/s bf16 dense figure
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--qp", type=int, default=37)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", action="store_true", help="also time the PCIe-inclusive loop of inference/kernel.cu:89-101")
+    return ap.parse_args()
+
+
+def cpu_baseline(qp, h, w):
+    """float32 restatement of training/model.py (model_blu) on the host cores, bounded sample."""
+    import torch
+    from oracle import float_model
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    m = synth.synth_model(qp)
+    _, anc = synth.synth_frames(h, w, qp)
+    ws, bs, blu = float_model.dequantise(m, quant_tables.QUANT_ROWS[qp])
+    float_model.forward_float(ws, bs, blu, anc[0][:64, :64].copy())     # warm-up (configs[0] shape)
+    t0 = time.perf_counter()
+    float_model.forward_float(ws, bs, blu, anc[0])
+    first = time.perf_counter() - t0
+    reps = max(1, min(5, int(12.0 / max(first, 1e-3))))
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        float_model.forward_float(ws, bs, blu, anc[0])
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(h * w / med / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x one {w}x{h} Y frame, float32 torch-CPU restatement of training/model.py model_blu, "
+                      f"median {med:.3f} s/frame"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only: barrier + max of the elapsed time
+        dist.init_process_group(backend="gloo")
+    lib = capi.load()
+    ndev = C.c_int()
+    capi.check(lib.qcnn_device_count(C.byref(ndev)))
+    dev = local_rank % max(ndev.value, 1)
+
+    h, w, qp, B = a.height, a.width, a.qp, a.batch
+    hw = h * w
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    # distinct frames per rank and per slot: rank r owns frames r*B .. r*B+B-1 of the synthetic clip
+    _, anc = synth.synth_frames(h, w, qp, frames=min(B, 4), seed=0x51434E4E + rank)
+    net = qvrcnn(dev, 1, 1, h, w)
+    net.load_static_para(mb)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    capi.check(lib.qcnn_dev_alloc(C.byref(d_in), B * hw))
+    capi.check(lib.qcnn_dev_alloc(C.byref(d_out), B * hw))
+    for i in range(B):
+        f = np.ascontiguousarray(anc[i % anc.shape[0]])
+        capi.check(lib.qcnn_dev_h2d(C.c_void_p(d_in.value + i * hw), f.ctypes.data, hw))
+
+    def step():
+        net.forward_blu_batch(d_in.value, d_out.value, B, hw)
+
+    def barrier():
+        capi.check(lib.qcnn_dev_sync())
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    net.set_timing(True)
+    net.kernel_times_us(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    capi.check(lib.qcnn_dev_sync())
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t.item())
+    ka_us, kb_us, passes = net.kernel_times_us(reset=True)
+    net.set_timing(False)
+
+    # the timed output must be the real thing: check frame 0 of the last step against the oracle
+    # on rank 0 (outside the timed region; bounded: one 64-row band at full width)
+    parity = None
+    e2e = None
+    if rank == 0:
+        from oracle import c_oracle
+        rec = np.empty((h, w), np.uint8)
+        capi.check(lib.qcnn_dev_d2h(rec.ctypes.data, d_out, hw))
+        band = min(h, 96)
+        rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[0][:band]))
+        keep = band - 6 if band < h else band                # rows whose 13x13 support lies inside the band
+        parity = bool(np.array_equal(rec[:keep], rec_o[:keep]))
+        if a.e2e:
+            host_in = np.ascontiguousarray(anc[0])
+            host_out = np.empty_like(host_in)
+            net.bind_io(0, 0)
+            for _ in range(3):
+                net.load_data(host_in); net.forward_blu(); net.download()
+            n = 20
+            t1 = time.perf_counter()
+            for _ in range(n):
+                net.load_data(host_in)     # blocking H2D   (inference/kernel.cu:93)
+                net.forward_blu()          #                (inference/kernel.cu:94)
+                host_out = net.download()  # sync + D2H     (inference/kernel.cu:95-96)
+            e2e = n * hw / (time.perf_counter() - t1) / 1e6
+
+    if rank == 0:
+        pixels = float(world) * a.steps * B * hw
+        value = pixels / elapsed / 1e6
+        # dominant kernel: k_c1c2 (C1 + C2_1 + C2_2 = 45 632 of the 54 512 MAC/pixel)
+        macs_a = sum(k * k * ci * co for _, k, ci, co in LAYERS[:3])
+        ops_a = 2.0 * macs_a * hw
+        achieved = ops_a / (ka_us * 1e-6) / 1e12 if ka_us > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("height") == h and tj.get("width") == w:
+                    traffic = tj.get("k_c1c2_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s, forward_blu on 1920x1080 Y frames, QP37 int8 QVRCNN" if (h, w, qp) == (1080, 1920, 37)
+                      else f"Mpixels/s, forward_blu on {w}x{h} Y frames, QP{qp} int8 QVRCNN",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {w}x{h} Y frame, QP{qp} int8, frames resident in HBM",
+                       "frames_per_step_per_gpu": B, "frame": [h, w], "qp": qp, "sharding": f"frames over {world} GPU(s), no collective"},
+            "roofline": {"bound": "mfma", "kernel": "k_c1c2 (I1.ppro + C1 + C2_1 + C2_2 + concat)",
+                         "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic,
+                         "note": "int8 ops (2 per MAC); algorithmic 91 264 ops/pixel for this kernel x %d pixels per launch; "
+                                 "avg launch %.1f us (k_c3c4: %.1f us) over %d launches, HIP events on the engine stream"
+                                 % (hw, ka_us, kb_us, passes),
+                         "whole_pass_frac": round((2.0 * MACS_PER_PIXEL * hw / ((ka_us + kb_us) * 1e-6) / 1e12) / PEAK_INT8_TOPS, 4)
+                                            if ka_us + kb_us > 0 else None},
+            "parity_vs_oracle": parity,
+        }
+        if e2e is not None:
+            out["pcie_inclusive_mpixels_s"] = round(e2e, 2)
+        if not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(qp, h, w)
+            except Exception as ex:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out))
+    capi.check(lib.qcnn_dev_free(d_in))
+    capi.check(lib.qcnn_dev_free(d_out))
+    net.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

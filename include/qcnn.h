@@ -72,6 +72,11 @@ int qcnn_upload_async(qcnn_t *e, const uint8_t *host_y);
  * on the engine stream (asynchronous; follow with qcnn_sync or qcnn_download). */
 int qcnn_forward_blu(qcnn_t *e);
 
+/* The frame loop of inference/kernel.cu:91-97 for frames already resident in HBM: runs
+ * qcnn_forward_blu on `nframes` frames read from dev_y + i*stride and written to dev_rec +
+ * i*stride (stride in bytes, >= height*width).  Asynchronous on the engine stream. */
+int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride);
+
 /* The same pass run layer by layer through the qcnn_op_* kernels below, materialising every
  * buffer of the reference (x_ppro, u, v, conc) in the reference's layouts: the tap/debug mode
  * (the role of MEM_DBG / viewmem, inference/cnn.cu:203-248). */

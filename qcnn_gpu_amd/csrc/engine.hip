@@ -406,6 +406,23 @@ int qcnn_forward_blu(qcnn_t *e)
     return QCNN_OK;
 }
 
+int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride)
+{
+    if (!e || !dev_y || !dev_rec) return fail(QCNN_E_ARG, "null argument");
+    if (nframes < 0 || stride < e->HW) return fail(QCNN_E_ARG, "bad batch: nframes=%d stride=%zu", nframes, stride);
+    const uint8_t *keep_y = e->bound_y;
+    uint8_t *keep_rec = e->bound_rec;
+    int rc = QCNN_OK;
+    for (int i = 0; i < nframes && rc == QCNN_OK; ++i) {
+        e->bound_y = static_cast<const uint8_t *>(dev_y) + (size_t)i * stride;
+        e->bound_rec = static_cast<uint8_t *>(dev_rec) + (size_t)i * stride;
+        rc = qcnn_forward_blu(e);
+    }
+    e->bound_y = keep_y;
+    e->bound_rec = keep_rec;
+    return rc;
+}
+
 int qcnn_forward_blu_layered(qcnn_t *e)
 {
     if (!e) return fail(QCNN_E_ARG, "null engine");

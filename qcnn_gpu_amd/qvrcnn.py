@@ -67,6 +67,11 @@ class qvrcnn:
         capi.check(self._lib.qcnn_forward_blu_layered(self._h))
         return 0
 
+    def forward_blu_batch(self, dev_y: int, dev_rec: int, nframes: int, stride: int = 0) -> int:
+        capi.check(self._lib.qcnn_forward_blu_batch(self._h, C.c_void_p(dev_y), C.c_void_p(dev_rec), nframes,
+                                                    stride or self.height * self.width))
+        return 0
+
     def synchronize(self) -> None:
         capi.check(self._lib.qcnn_sync(self._h))
 
