@@ -190,6 +190,10 @@ static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
         const long long top = ((long long)(q.blu + q.bias) * q.mul) >> q.shift;
         if (top != 127) return false;
         if ((long long)(q.blu + q.bias) * q.mul >= (1ll << 31)) return false;
+        // pre-shifted form used by the kernels: 24-bit multiplier, product below 2^32
+        const int k = (q.shift <= 16 ? 16 : 24) - q.shift;
+        if (((long long)q.mul << k) >= (1ll << 23)) return false;
+        if (((long long)(q.blu + q.bias) * q.mul << k) >= (1ll << 32)) return false;
     }
     return true;
 }

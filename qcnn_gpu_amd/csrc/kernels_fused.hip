@@ -36,11 +36,30 @@ __device__ __forceinline__ v16i mfma32(v4i a, v4i b, v16i c)
 }
 
 // Integer requantiser, valid when the host-side proof holds (see engine.hip, prove_integer_path):
-// s is acc + bias, exactly what the reference's float u holds.
-__device__ __forceinline__ int requant_int(int s, const Requant &q)
+// s is acc + bias, exactly what the reference's float u holds.  Both clip arms are one v_med3
+// (requant(blu) == 127 is part of the proof), and mul/cmul are pre-shifted on the host so that
+// the quotient ((v + bias) * mul) >> shift is a whole byte (byte 2 or 3) of the 32-bit product:
+// the shift is then done by the byte-permute that packs four channels into a dword.
+// The clamp is inline asm (no integer med3 builtin exists and the compiler only forms one from
+// constant bounds).  hipcc does not pad the MFMA-result -> VALU-read hazard for instructions
+// inside an asm statement, so every epilogue that applies med3i to accumulators first calls
+// mfma_drain(): 20 wait states, more than the 11 an 8-pass MFMA needs, fenced so that nothing is
+// scheduled across it.
+__device__ __forceinline__ void mfma_drain()
 {
-    const int v = min(max(s, 0), q.blu);          // v_med3_i32: both clip arms (requant(blu) == 127)
-    return (__mul24(v, q.mul) + q.cmul) >> q.shift;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ int med3i(int x, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned requant_prod(int s, const Requant &q)
+{
+    return __umul24((unsigned)med3i(s, q.blu), (unsigned)q.mulk) + (unsigned)q.cmulk;
 }
 // Literal float32 pipeline of ConvForward_static + CHW2CHW_VECT_C_QUANT_BLU.
 __device__ __forceinline__ int requant_float(int acc, float bf, const Requant &q)
@@ -49,12 +68,6 @@ __device__ __forceinline__ int requant_float(int acc, float bf, const Requant &q
     if (t > q.bluf) return 127;
     if (t < 0.f) return 0;
     return (int)((unsigned)((int)t + q.bias) * (unsigned)q.mul) >> q.shift;
-}
-template <bool EXACT>
-__device__ __forceinline__ int requant(int acc, float bf, const Requant &q)
-{
-    if constexpr (EXACT) return requant_float(acc, bf, q);
-    else return requant_int(acc, q);
 }
 
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
@@ -65,11 +78,47 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// Requantises four consecutive channels (accumulators a0..a3, float biases only used by the
+// EXACT variant) and packs them into one dword.
+template <bool EXACT>
+__device__ __forceinline__ unsigned quant4(int a0, int a1, int a2, int a3, float b0, float b1, float b2, float b3,
+                                           const Requant &q)
+{
+    if constexpr (EXACT) {
+        return pack4(requant_float(a0, b0, q), requant_float(a1, b1, q), requant_float(a2, b2, q),
+                     requant_float(a3, b3, q));
+    } else {
+        const unsigned lo = __builtin_amdgcn_perm(requant_prod(a1, q), requant_prod(a0, q), q.sel2);
+        const unsigned hi = __builtin_amdgcn_perm(requant_prod(a3, q), requant_prod(a2, q), q.sel2);
+        return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    }
+}
+
 // Byte offset of 16-byte channel chunk `chunk` (0..3) inside the 64-byte pixel at LDS column
-// `col`: bit 1 of the chunk index is flipped on every other group of 4 columns, which makes the
-// 16-lane groups of a ds_read_b128 B-fragment read (16 pixels x 4 chunks) hit 16 distinct
-// 16-byte bank slots.
-__device__ __forceinline__ int swz(int chunk, int col) { return (chunk * 16) ^ (((col >> 2) & 1) << 5); }
+// `col`: the chunk position is rotated by col/2.  With it the 16-lane groups of a ds_read_b128
+// B-fragment read (16 consecutive pixels x 4 chunks) hit 16 distinct 16-byte bank slots, and the
+// 8-lane groups of the ds_write_b128 that fills the tile (8 consecutive pixels, one chunk) hit 8
+// distinct slots of the 128-byte write window.
+__device__ __forceinline__ int swz(int chunk, int col) { return ((chunk + (col >> 1)) & 3) * 16; }
+
+// A fragments of one kernel column s of the C2 stage: C2_2 rows r = 0..4 and, for the three inner
+// columns, C2_1 rows r' = 0..2 x two 16-channel tiles.
+struct C2Weights {
+    v4i f22[5];
+    v4i f21[3][2];
+};
+__device__ __forceinline__ void load_c2_weights(const v4i *w22, const v4i *w21, int s, C2Weights &o)
+{
+#pragma unroll
+    for (int r = 0; r < 5; ++r) o.f22[r] = w22[(s * 5 + r) * 64];
+    if (s >= 1 && s <= 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o.f21[r][0] = w21[(((s - 1) * 3 + r) * 2 + 0) * 64];
+            o.f21[r][1] = w21[(((s - 1) * 3 + r) * 2 + 1) * 64];
+        }
+    }
+}
 
 // =========================================================================================
 // Kernel A
@@ -88,6 +137,11 @@ __global__ __launch_bounds__(256, 2) void k_c1c2(const FusedArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int H = a.H, W = a.W;
+    // C2 weights of kernel column 0: requested now, consumed after the C1 phase
+    const v4i *w22 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C2W22) + lane;
+    const v4i *w21 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C2W21) + lane;
+    C2Weights w0;
+    load_c2_weights(w22, w21, 0, w0);
 
     // ---- phase 0: Y tile, rows y0-4 .. y0+TH+4, cols x0-4 .. x0+TW+3; I1.ppro is the ^0x80 ----
     for (int idx = tid; idx < YR * YC; idx += 256) {
@@ -155,33 +209,28 @@ __global__ __launch_bounds__(256, 2) void k_c1c2(const FusedArgs a)
             const v4i B = *reinterpret_cast<const v4i *>(sY16 + ((i + 3 * h) * C1C + j) * 16);
             v16i d0 = mfma32(A0, B, bias0);
             v16i d1 = mfma32(A1, B, bias1);
+            mfma_drain();
             const int gy = y0 - 2 + i, gx = x0 - 2 + j;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
             v4i o0, o1;
             if constexpr (!EXACT) {
-                o0.x = pack4(requant_int(d0[0], q), requant_int(d0[1], q), requant_int(d0[2], q), requant_int(d0[3], q));
-                o0.y = pack4(requant_int(d0[4], q), requant_int(d0[5], q), requant_int(d0[6], q), requant_int(d0[7], q));
-                o0.z = pack4(requant_int(d0[8], q), requant_int(d0[9], q), requant_int(d0[10], q), requant_int(d0[11], q));
-                o0.w = pack4(requant_int(d0[12], q), requant_int(d0[13], q), requant_int(d0[14], q), requant_int(d0[15], q));
-                o1.x = pack4(requant_int(d1[0], q), requant_int(d1[1], q), requant_int(d1[2], q), requant_int(d1[3], q));
-                o1.y = pack4(requant_int(d1[4], q), requant_int(d1[5], q), requant_int(d1[6], q), requant_int(d1[7], q));
-                o1.z = pack4(requant_int(d1[8], q), requant_int(d1[9], q), requant_int(d1[10], q), requant_int(d1[11], q));
-                o1.w = pack4(requant_int(d1[12], q), requant_int(d1[13], q), requant_int(d1[14], q), requant_int(d1[15], q));
+                o0.x = quant4<false>(d0[0], d0[1], d0[2], d0[3], 0.f, 0.f, 0.f, 0.f, q);
+                o0.y = quant4<false>(d0[4], d0[5], d0[6], d0[7], 0.f, 0.f, 0.f, 0.f, q);
+                o0.z = quant4<false>(d0[8], d0[9], d0[10], d0[11], 0.f, 0.f, 0.f, 0.f, q);
+                o0.w = quant4<false>(d0[12], d0[13], d0[14], d0[15], 0.f, 0.f, 0.f, 0.f, q);
+                o1.x = quant4<false>(d1[0], d1[1], d1[2], d1[3], 0.f, 0.f, 0.f, 0.f, q);
+                o1.y = quant4<false>(d1[4], d1[5], d1[6], d1[7], 0.f, 0.f, 0.f, 0.f, q);
+                o1.z = quant4<false>(d1[8], d1[9], d1[10], d1[11], 0.f, 0.f, 0.f, 0.f, q);
+                o1.w = quant4<false>(d1[12], d1[13], d1[14], d1[15], 0.f, 0.f, 0.f, 0.f, q);
             } else {
-                int r0[16], r1[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    r0[k] = requant_float(d0[k], bf0[k], q);
-                    r1[k] = requant_float(d1[k], bf1[k], q);
-                }
-                o0.x = pack4(r0[0], r0[1], r0[2], r0[3]);
-                o0.y = pack4(r0[4], r0[5], r0[6], r0[7]);
-                o0.z = pack4(r0[8], r0[9], r0[10], r0[11]);
-                o0.w = pack4(r0[12], r0[13], r0[14], r0[15]);
-                o1.x = pack4(r1[0], r1[1], r1[2], r1[3]);
-                o1.y = pack4(r1[4], r1[5], r1[6], r1[7]);
-                o1.z = pack4(r1[8], r1[9], r1[10], r1[11]);
-                o1.w = pack4(r1[12], r1[13], r1[14], r1[15]);
+                o0.x = quant4<true>(d0[0], d0[1], d0[2], d0[3], bf0[0], bf0[1], bf0[2], bf0[3], q);
+                o0.y = quant4<true>(d0[4], d0[5], d0[6], d0[7], bf0[4], bf0[5], bf0[6], bf0[7], q);
+                o0.z = quant4<true>(d0[8], d0[9], d0[10], d0[11], bf0[8], bf0[9], bf0[10], bf0[11], q);
+                o0.w = quant4<true>(d0[12], d0[13], d0[14], d0[15], bf0[12], bf0[13], bf0[14], bf0[15], q);
+                o1.x = quant4<true>(d1[0], d1[1], d1[2], d1[3], bf1[0], bf1[1], bf1[2], bf1[3], q);
+                o1.y = quant4<true>(d1[4], d1[5], d1[6], d1[7], bf1[4], bf1[5], bf1[6], bf1[7], q);
+                o1.z = quant4<true>(d1[8], d1[9], d1[10], d1[11], bf1[8], bf1[9], bf1[10], bf1[11], q);
+                o1.w = quant4<true>(d1[12], d1[13], d1[14], d1[15], bf1[12], bf1[13], bf1[14], bf1[15], q);
             }
             if (!inside) {  // zero padding of the C2 input: C1 output does not exist outside the frame
                 o0 = v4i{0, 0, 0, 0};
@@ -217,22 +266,16 @@ __global__ __launch_bounds__(256, 2) void k_c1c2(const FusedArgs a)
                 acc22[y] = b2;
             }
         }
-        const v4i *w22 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C2W22) + lane;
-        const v4i *w21 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C2W21) + lane;
         const unsigned char *rowbase = sC1 + (R0 * C1C + cb + c) * 64;
+        // The A fragments of kernel column s+1 are requested from L2 before the MFMAs of column s
+        // are issued (the sched_barrier pins the requests there), so their latency is covered by
+        // ~40-90 MFMAs instead of being paid fragment by fragment.
+        C2Weights cur = w0, nxt;
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             const bool inner_s = s >= 1 && s <= 3;
-            v4i f22[5], f21[3][2];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) f22[r] = w22[(s * 5 + r) * 64];
-            if (inner_s) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    f21[r][0] = w21[(((s - 1) * 3 + r) * 2 + 0) * 64];
-                    f21[r][1] = w21[(((s - 1) * 3 + r) * 2 + 1) * 64];
-                }
-            }
+            if (s < 4) load_c2_weights(w22, w21, s + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned char *colbase = rowbase + s * 64 + swz(g, cb + c + s);
 #pragma unroll
             for (int yy = 0; yy < 12; ++yy) {
@@ -241,17 +284,19 @@ __global__ __launch_bounds__(256, 2) void k_c1c2(const FusedArgs a)
                 for (int r = 0; r < 5; ++r) {
                     const int y = yy - r;
                     if (y >= 0 && y < 8) {
-                        acc22[y] = mfma16(f22[r], B, acc22[y]);
+                        acc22[y] = mfma16(cur.f22[r], B, acc22[y]);
                         if (inner_s && r >= 1 && r <= 3) {
-                            acc21[0][y] = mfma16(f21[r - 1][0], B, acc21[0][y]);
-                            acc21[1][y] = mfma16(f21[r - 1][1], B, acc21[1][y]);
+                            acc21[0][y] = mfma16(cur.f21[r - 1][0], B, acc21[0][y]);
+                            acc21[1][y] = mfma16(cur.f21[r - 1][1], B, acc21[1][y]);
                         }
                     }
                 }
             }
+            if (s < 4) cur = nxt;
         }
         // epilogue: lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel tile = 12
         // consecutive bytes at position 12g of the pixel in the internal channel order.
+        mfma_drain();
         const Requant q21 = a.rq[1], q22 = a.rq[2];
         float bf[12];
         if constexpr (EXACT) {
@@ -269,12 +314,12 @@ __global__ __launch_bounds__(256, 2) void k_c1c2(const FusedArgs a)
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
             const int gy = y0 + R0 + y;
-            const unsigned d0 = pack4(requant<EXACT>(acc21[0][y][0], bf[0], q21), requant<EXACT>(acc21[0][y][1], bf[1], q21),
-                                      requant<EXACT>(acc21[0][y][2], bf[2], q21), requant<EXACT>(acc21[0][y][3], bf[3], q21));
-            const unsigned d1 = pack4(requant<EXACT>(acc21[1][y][0], bf[4], q21), requant<EXACT>(acc21[1][y][1], bf[5], q21),
-                                      requant<EXACT>(acc21[1][y][2], bf[6], q21), requant<EXACT>(acc21[1][y][3], bf[7], q21));
-            const unsigned d2 = pack4(requant<EXACT>(acc22[y][0], bf[8], q22), requant<EXACT>(acc22[y][1], bf[9], q22),
-                                      requant<EXACT>(acc22[y][2], bf[10], q22), requant<EXACT>(acc22[y][3], bf[11], q22));
+            const unsigned d0 = quant4<EXACT>(acc21[0][y][0], acc21[0][y][1], acc21[0][y][2], acc21[0][y][3], bf[0], bf[1],
+                                              bf[2], bf[3], q21);
+            const unsigned d1 = quant4<EXACT>(acc21[1][y][0], acc21[1][y][1], acc21[1][y][2], acc21[1][y][3], bf[4], bf[5],
+                                              bf[6], bf[7], q21);
+            const unsigned d2 = quant4<EXACT>(acc22[y][0], acc22[y][1], acc22[y][2], acc22[y][3], bf[8], bf[9], bf[10],
+                                              bf[11], q22);
             if (gy < H && gx < W) {
                 unsigned *dst = reinterpret_cast<unsigned *>(a.conc1 + ((size_t)gy * W + gx) * 48 + 12 * g);
                 dst[0] = d0;
@@ -303,6 +348,23 @@ __global__ __launch_bounds__(256, 2) void k_c3c4(const FusedArgs a)
     const int H = a.H, W = a.W;
     const int c = lane & 15, g = lane >> 4;
     const int gk = g == 3 ? 0 : g;  // k-group 3 multiplies zero weights; it re-reads chunk 0
+
+    // All 14 A fragments of this kernel (C3_1: 9, C3_2: 2, C4: 3) are requested up front; they are
+    // first used after the tile load below, which covers their latency.
+    v4i f31[3][3], f32[2], f4[3];
+    {
+        const v4i *w31 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C3W31) + lane;
+        const v4i *w32 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C3W32) + lane;
+        const v4i *w4 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C4W) + lane;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) f31[s][r] = w31[(s * 3 + r) * 64];
+            f4[s] = w4[s * 64];
+        }
+        f32[0] = w32[0];
+        f32[1] = w32[64];
+    }
 
     // ---- phase 0: conc1 tile, rows y0-2 .. y0+TH+1, cols x0-2 .. x0+TW+1, zero outside ----
     {
@@ -347,18 +409,9 @@ __global__ __launch_bounds__(256, 2) void k_c3c4(const FusedArgs a)
                 acc32[1][y] = b2;
             }
         }
-        const v4i *w31 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C3W31) + lane;
-        const v4i *w32 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C3W32) + lane;
         const unsigned char *rowbase = sIn + (R0 * INC + cb + c) * PX + gk * 16;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            v4i f31[3], f32[2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) f31[r] = w31[(s * 3 + r) * 64];
-            if (s == 1) {
-                f32[0] = w32[0];
-                f32[1] = w32[64];
-            }
 #pragma unroll
             for (int yy = 0; yy < 12; ++yy) {
                 const v4i B = *reinterpret_cast<const v4i *>(rowbase + (yy * INC + s) * PX);
@@ -366,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void k_c3c4(const FusedArgs a)
                 for (int r = 0; r < 3; ++r) {
                     const int y = yy - r;
                     if (y >= 0 && y < 10) {
-                        acc31[y] = mfma16(f31[r], B, acc31[y]);
+                        acc31[y] = mfma16(f31[s][r], B, acc31[y]);
                         if (s == 1 && r == 1) {
                             acc32[0][y] = mfma16(f32[0], B, acc32[0][y]);
                             acc32[1][y] = mfma16(f32[1], B, acc32[1][y]);
@@ -375,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_c3c4(const FusedArgs a)
                 }
             }
         }
+        mfma_drain();
         const Requant q31 = a.rq[3], q32 = a.rq[4];
         float bf[12];
         if constexpr (EXACT) {
@@ -394,12 +448,11 @@ __global__ __launch_bounds__(256, 2) void k_c3c4(const FusedArgs a)
         for (int y = 0; y < 10; ++y) {
             const int i = R0 + y;
             const int gy = y0 - 1 + i;
-            unsigned d0 = pack4(requant<EXACT>(acc31[y][0], bf[0], q31), requant<EXACT>(acc31[y][1], bf[1], q31),
-                                requant<EXACT>(acc31[y][2], bf[2], q31), requant<EXACT>(acc31[y][3], bf[3], q31));
-            unsigned d1 = pack4(requant<EXACT>(acc32[0][y][0], bf[4], q32), requant<EXACT>(acc32[0][y][1], bf[5], q32),
-                                requant<EXACT>(acc32[0][y][2], bf[6], q32), requant<EXACT>(acc32[0][y][3], bf[7], q32));
-            unsigned d2 = pack4(requant<EXACT>(acc32[1][y][0], bf[8], q32), requant<EXACT>(acc32[1][y][1], bf[9], q32),
-                                requant<EXACT>(acc32[1][y][2], bf[10], q32), requant<EXACT>(acc32[1][y][3], bf[11], q32));
+            unsigned d0 = quant4<EXACT>(acc31[y][0], acc31[y][1], acc31[y][2], acc31[y][3], bf[0], bf[1], bf[2], bf[3], q31);
+            unsigned d1 = quant4<EXACT>(acc32[0][y][0], acc32[0][y][1], acc32[0][y][2], acc32[0][y][3], bf[4], bf[5], bf[6],
+                                        bf[7], q32);
+            unsigned d2 = quant4<EXACT>(acc32[1][y][0], acc32[1][y][1], acc32[1][y][2], acc32[1][y][3], bf[8], bf[9], bf[10],
+                                        bf[11], q32);
             if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) d0 = d1 = d2 = 0;  // zero padding of the C4 input
             unsigned *dst = reinterpret_cast<unsigned *>(sC3 + (i * C3C + jj) * PX + 12 * g);
             dst[0] = d0;
@@ -414,8 +467,6 @@ __global__ __launch_bounds__(256, 2) void k_c3c4(const FusedArgs a)
     // D_{y+2}[2] stays inside one lane.  Wave = 9 output rows x 16 columns. ----
     {
         const int cb = (wv & 1) * 16, O0 = (wv >> 1) * 9;
-        const v4i *w4 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C4W) + lane;
-        const v4i f4[3] = {w4[0], w4[64], w4[128]};
         const unsigned char *rowbase = sC3 + (O0 * C3C + cb + c) * PX + gk * 16;
         int out[9];
 #pragma unroll
