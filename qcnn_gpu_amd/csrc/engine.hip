@@ -50,7 +50,7 @@ static size_t model_bytes()
 using namespace qcnn;
 
 struct qcnn_engine {
-    int gpu = 0, H = 0, W = 0;
+    int gpu = 0, H = 0, W = 0, ncu = 256;
     size_t HW = 0;
     hipStream_t stream = nullptr;
     // I1
@@ -63,6 +63,7 @@ struct qcnn_engine {
     int *bias_i = nullptr;
     float *bias_f = nullptr;
     unsigned long long *sse_dev = nullptr;
+    unsigned long long *dbg = nullptr;  // diagnostic builds only
     // layered path (allocated on first use)
     bool layered_ready = false;
     int8_t *x_ppro = nullptr;
@@ -248,6 +249,12 @@ static FusedArgs fused_args(qcnn_engine *e)
     a.bias_f = e->bias_f;
     a.H = e->H;
     a.W = e->W;
+    a.ncu = e->ncu;
+    a.dbg = e->dbg;
+    {
+        const char *sb = getenv("QCNN_STAMP_BLOCK");
+        a.dbg_block = sb ? atoi(sb) : 0;
+    }
     for (int l = 0; l < 6; ++l) a.rq[l] = e->rq[l];
     return a;
 }
@@ -281,7 +288,10 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (gpu < 0 || gpu >= ndev) return fail(QCNN_E_ARG, "gpu %d out of range (%d devices)", gpu, ndev);
     HIP_TRY(hipSetDevice(gpu));  // qvrcnn.cu:6
+    int ncu = 0;
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, gpu));
     qcnn_engine *e = new qcnn_engine;
+    e->ncu = ncu > 0 ? ncu : 256;
     e->gpu = gpu;
     e->H = height;
     e->W = width;
@@ -303,6 +313,10 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY_E(hipMalloc(&e->bias_i, 161 * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->bias_f, 161 * sizeof(float)));
     HIP_TRY_E(hipMalloc(&e->sse_dev, sizeof(unsigned long long)));
+#ifdef QCNN_STAMPS
+    HIP_TRY_E(hipMalloc(&e->dbg, 16 * 128 * sizeof(unsigned long long)));
+    HIP_TRY_E(hipMemset(e->dbg, 0, 16 * 128 * sizeof(unsigned long long)));
+#endif
     for (int l = 0; l < 6; ++l) HIP_TRY_E(hipMalloc(&e->w_file[l], wsize(l)));
 #undef HIP_TRY_E
     const char *fx = getenv("QCNN_FORCE_EXACT");
@@ -324,6 +338,7 @@ int qcnn_destroy(qcnn_t *e)
     (void)hipFree(e->bias_i);
     (void)hipFree(e->bias_f);
     (void)hipFree(e->sse_dev);
+    (void)hipFree(e->dbg);
     (void)hipFree(e->x_ppro);
     for (int l = 0; l < 6; ++l) {
         (void)hipFree(e->u[l]);
@@ -612,6 +627,18 @@ int qcnn_kernel_times_us(qcnn_t *e, double *k_c1c2_us, double *k_c3c4_us, int *p
     if (reset) e->ev_used = 0;
     return QCNN_OK;
 }
+
+#ifdef QCNN_STAMPS
+// diagnostic builds only: copies the cycle stamps (16 waves x 128 slots) of the last kernels to host
+int qcnn_debug_stamps(qcnn_t *e, unsigned long long *host_out)
+{
+    if (!e || !host_out) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(host_out, e->dbg, 16 * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(e->dbg, 0, 16 * 128 * sizeof(unsigned long long)));
+    return QCNN_OK;
+}
+#endif
 
 // ---- layer level ---------------------------------------------------------------------------
 int qcnn_op_ppro(const void *x, void *x_ppro, size_t n, void *stream)

@@ -1,0 +1,127 @@
+// The production forward pass of qvrcnn::forward_blu (inference/qvrcnn.cu:168-242) as two fused
+// gfx950 kernels built on the int8 MFMA instructions:
+//
+//   k_c1c2 : Y tile -> I1.ppro -> C1 conv+bias -> ReLU/clip/requant -> (C2_1 || C2_2) conv+bias ->
+//            ReLU/clip/requant -> concat, written once to HBM as [H][W][48] int8
+//   k_c3c4 : conc1 tile -> (C3_1 || C3_2) conv+bias -> ReLU/clip/requant -> concat (LDS only) ->
+//            C4 conv+bias -> applyRes_y residual add + clamp -> I1.x_rec
+//
+// Every convolution is an implicit GEMM D[channel][pixel] = W[channel][k] * X[k][pixel]: the
+// weights are the MFMA A operand (pre-packed on the host in lane order), the activations the B
+// operand, read from an LDS tile whose pixels hold their channels contiguously, so a B fragment
+// is one 16-byte LDS read per lane.  A wave keeps the B fragment of one (input row, column
+// shift) in registers and reuses it for every kernel row r that maps it to one of the wave's
+// output rows, and keeps the A fragments of one kernel column in registers while it sweeps the
+// input rows; that is what holds LDS and L1 traffic per MFMA low.
+//
+// Two instantiations of each kernel exist.  EXACT=false is used when the host has proved, from
+// the loaded weights, that no accumulator or bias can reach 2^24: then the reference's float32
+// pipeline (float(acc) + float(b), float compares, (int) truncation) is identical to integer
+// arithmetic and the bias is folded into the MFMA accumulator.  EXACT=true replays the float32
+// pipeline literally and is bit-exact for every possible model.
+#pragma once
+#include "qcnn_internal.h"
+
+namespace qcnn {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v4i mfma16(v4i a, v4i b, v4i c)
+{
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ v16i mfma32(v4i a, v4i b, v16i c)
+{
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+}
+
+// Integer requantiser, valid when the host-side proof holds (see engine.hip, prove_integer_path):
+// s is acc + bias, exactly what the reference's float u holds.  Both clip arms are one v_med3
+// (requant(blu) == 127 is part of the proof), and mul/cmul are pre-shifted on the host so that
+// the quotient ((v + bias) * mul) >> shift is a whole byte (byte 2 or 3) of the 32-bit product:
+// the shift is then done by the byte-permute that packs four channels into a dword.
+// The clamp is inline asm (no integer med3 builtin exists and the compiler only forms one from
+// constant bounds).  hipcc does not pad the MFMA-result -> VALU-read hazard for instructions
+// inside an asm statement, so every epilogue that applies med3i to accumulators first calls
+// mfma_drain(): 20 wait states, more than the 11 an 8-pass MFMA needs, fenced so that nothing is
+// scheduled across it.
+__device__ __forceinline__ void mfma_drain()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ int med3i(int x, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned requant_prod(int s, const Requant &q)
+{
+    return __umul24((unsigned)med3i(s, q.blu), (unsigned)q.mulk) + (unsigned)q.cmulk;
+}
+// Literal float32 pipeline of ConvForward_static + CHW2CHW_VECT_C_QUANT_BLU.
+__device__ __forceinline__ int requant_float(int acc, float bf, const Requant &q)
+{
+    const float t = (float)acc + bf;
+    if (t > q.bluf) return 127;
+    if (t < 0.f) return 0;
+    return (int)((unsigned)((int)t + q.bias) * (unsigned)q.mul) >> q.shift;
+}
+
+__device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
+{
+    // low bytes of a,b,c,d -> one dword (the store-to-char truncation of the reference)
+    const unsigned lo = __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x0c0c0400u);
+    const unsigned hi = __builtin_amdgcn_perm((unsigned)d, (unsigned)c, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+// Requantises four consecutive channels (accumulators a0..a3, float biases only used by the
+// EXACT variant) and packs them into one dword.
+template <bool EXACT>
+__device__ __forceinline__ unsigned quant4(int a0, int a1, int a2, int a3, float b0, float b1, float b2, float b3,
+                                           const Requant &q)
+{
+    if constexpr (EXACT) {
+        return pack4(requant_float(a0, b0, q), requant_float(a1, b1, q), requant_float(a2, b2, q),
+                     requant_float(a3, b3, q));
+    } else {
+        const unsigned lo = __builtin_amdgcn_perm(requant_prod(a1, q), requant_prod(a0, q), q.sel2);
+        const unsigned hi = __builtin_amdgcn_perm(requant_prod(a3, q), requant_prod(a2, q), q.sel2);
+        return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    }
+}
+
+// Byte offset of 16-byte channel chunk `chunk` (0..3) inside the 64-byte pixel at LDS column
+// `col`: the chunk position is rotated by col/2.  With it the 16-lane groups of a ds_read_b128
+// B-fragment read (16 consecutive pixels x 4 chunks) hit 16 distinct 16-byte bank slots, and the
+// 8-lane groups of the ds_write_b128 that fills the tile (8 consecutive pixels, one chunk) hit 8
+// distinct slots of the 128-byte write window.
+__device__ __forceinline__ int swz(int chunk, int col) { return ((chunk + (col >> 1)) & 3) * 16; }
+
+
+// Diagnostic build only (-DQCNN_STAMPS): per-wave cycle stamps of workgroup 0, written to a debug
+// buffer that nothing else reads.  Never compiled into the shipped library.
+#ifdef QCNN_STAMPS
+#define QCNN_STAMP_SLOTS 128
+__device__ __forceinline__ void stamp(unsigned long long *dbg, int blk, int wv, int &idx)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    if (dbg && (int)(blockIdx.x + blockIdx.y * gridDim.x) == blk && (threadIdx.x & 63) == 0 && idx < QCNN_STAMP_SLOTS)
+        dbg[wv * QCNN_STAMP_SLOTS + idx] = t;
+    ++idx;
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define STAMP() stamp(a.dbg, a.dbg_block, wv, stamp_idx)
+#define STAMP_INIT() int stamp_idx = 0
+#else
+#define STAMP() do { } while (0)
+#define STAMP_INIT() do { } while (0)
+#endif
+
+}  // namespace qcnn

@@ -25,16 +25,19 @@ struct Requant {
 };
 
 // ---- fused kernel geometry -------------------------------------------------------------
-// Kernel A: Y -> C1 -> (C2_1 || C2_2) -> conc1 in HBM, one 16 x 32 output tile per workgroup.
+// Kernel A: Y -> C1 -> (C2_1 || C2_2) -> conc1 in HBM.  Persistent 512-thread workgroups walk
+// 16 x 32 output tiles; four producer waves fill a double-buffered C1 tile, four consumer waves
+// run the C2 stage on the other buffer.
 namespace ka {
 constexpr int TH = 16, TW = 32;
 constexpr int C1R = TH + 4, C1C = TW + 4;  // C1 output region held in LDS (halo 2)
-constexpr int YR = TH + 9, YC = TW + 8;    // plain Y tile rows/cols (halo 4, +1 row of slack)
-constexpr int Y16R = TH + 7;               // rows of the 16-byte-per-pixel im2col image
+constexpr int PROD_ROWS = C1R / 4;         // C1 region rows per producer wave
+constexpr int YWR = PROD_ROWS + 5, YWC = TW + 8;  // private Y tile of one producer (halo 4 + 1 slack row)
 constexpr int SC1_BYTES = C1R * C1C * 64;
-constexpr int SY16_BYTES = Y16R * C1C * 16;
-constexpr int SY_BYTES = (YR * YC + 15) / 16 * 16;
-constexpr int LDS_BYTES = SC1_BYTES + SY16_BYTES + SY_BYTES;
+constexpr int SYW_BYTES = YWR * YWC;
+constexpr int SW_BYTES = 43 * 1024;        // the 25 + 18 C2 A fragments
+constexpr int LDS_BYTES = 2 * SC1_BYTES + 4 * SYW_BYTES + SW_BYTES;
+static_assert(SYW_BYTES % 16 == 0 && YWC % 4 == 0, "private Y tiles are read as aligned dwords");
 }  // namespace ka
 
 // Kernel B: conc1 -> (C3_1 || C3_2) -> C4 -> residual add, one 18 x 30 output tile per workgroup.
@@ -69,7 +72,10 @@ struct FusedArgs {
     const int *bias_i;       // int32 biases, 6 layers concatenated: 64,32,16,16,32,1 (=161)
     const float *bias_f;     // same, converted to float as CovLayer::load_static_para does
     int H, W;
+    int ncu;                 // compute units of the device (grid size of the persistent kernel)
     Requant rq[QCNN_NUM_LAYERS];
+    unsigned long long *dbg; // cycle stamps of a diagnostic build, else null
+    int dbg_block;           // linear workgroup index that writes the stamps
 };
 
 // Offsets of each layer's biases inside bias_i / bias_f.
