@@ -1,0 +1,95 @@
+/*
+ * cnn.h -- the reference's layer API (inference/cnn.cuh:17-100) on top of the C ABI of qcnn.h.
+ * Same class names, same public members, same method names and argument meaning; the
+ * cudnnHandle_t / cudnnTensorDescriptor_t parameters are the stand-ins of mat.h.  Only the
+ * members of the static-quantised path are functional (load_static_para, ConvForward_static,
+ * quantize_out_blu, concat_blu, ppro, applyRes_y); the dynamic-quantisation members of the
+ * reference (load_para, ConvForward, quantize_out, concat ...) are declared and report
+ * "unsupported" through check().
+ */
+#ifndef QCNN_CNN_H
+#define QCNN_CNN_H
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "mat.h"
+
+class CovLayer {
+public:
+    CovLayer();
+    int build(qcnnHandle_t handle, qcnnTensorDescriptor_t xDesc, int batch, int height, int width, int inChannel,
+              int outChannel, int ksize);                                  /* inference/cnn.cu:13-66 */
+    int load_para(FILE *fp);                                               /* dynamic path: unsupported */
+    int load_static_para(FILE *fp);                                        /* inference/cnn.cu:90-112 */
+    int ConvForward(qcnnHandle_t handle, qcnnTensorDescriptor_t xDesc, void *x, void *workspace,
+                    size_t workspaceSize);                                 /* dynamic path: unsupported */
+    int ConvForward_static(qcnnHandle_t handle, qcnnTensorDescriptor_t xDesc, void *x, void *workspace,
+                           size_t workspaceSize);                          /* inference/cnn.cu:145-160 */
+    int activate(qcnnHandle_t handle);                                     /* unsupported */
+    int quantize_out(void *workspace);                                     /* unsupported */
+    int quantize_out_fix(int max_u);                                       /* unsupported */
+    int quantize_out_static(void);                                         /* unsupported */
+    int quantize_out_blu(void);                                            /* inference/cnn.cu:195-200 */
+    int viewmem(xwtype *x);                                                /* inference/cnn.cu:203-248 */
+    /* adopt buffers owned by a qcnn engine instead of allocating (used by class qvrcnn) */
+    int adopt(int batch, int height, int width, int inChannel, int outChannel, int ksize, void *w, void *b, void *u,
+              void *v);
+    ~CovLayer();
+
+    int batch, height, width, inChannel, outChannel, ksize;
+    int wSize, uSize, vSize;
+    size_t workspaceSize;
+    int max_u;
+    int step_w, step_y;
+    int blu;
+    int mul, shift;
+    float alpha = 1;
+    float beta = 0;
+    qcnnTensorDescriptor_t uDesc, vDesc;
+    void *w, *b, *b_adj;
+    void *u, *v;
+
+private:
+    bool owns_;
+};
+
+class ConcatLayer {
+public:
+    ConcatLayer(void);
+    int build(int batch, int height, int width, int inChannel1, int inChannel2);   /* inference/cnn.cu:268-283 */
+    int concat(CovLayer *C1, CovLayer *C2, void *workspace);                        /* unsupported */
+    int concat_blu(CovLayer *C1, CovLayer *C2);                                     /* inference/cnn.cu:375-394 */
+    int adopt(int batch, int height, int width, int inChannel1, int inChannel2, void *conc);
+    ~ConcatLayer();
+
+    int batch, height, width, inChannel1, inChannel2, outChannel;
+    qcnnTensorDescriptor_t concDesc;
+    void *conc;
+
+private:
+    bool owns_;
+};
+
+class InputLayer {
+public:
+    InputLayer(void);
+    int build(int batch, int channel, int height, int width);      /* inference/cnn.cu:414-438 */
+    int load(datatype *input);                                      /* inference/cnn.cu:439-443 */
+    int ppro(void);                                                 /* inference/cnn.cu:454-468 */
+    int applyRes(xwtype *res);                                      /* unsupported */
+    int applyRes_y(convtype *res, int mul, int shift);              /* inference/cnn.cu:530-535 */
+    int adopt(int batch, int channel, int height, int width, void *x, void *x_ppro, void *x_rec);
+    ~InputLayer(void);
+
+    int batch, height, width, inChannel, outChannel;
+    int inSize, outSize;
+    qcnnTensorDescriptor_t xDesc;
+    void *x, *x_ppro, *x_rec;
+
+private:
+    bool owns_;
+};
+
+#endif

@@ -1,0 +1,31 @@
+/*
+ * yuv_data.h -- the reference's YUV / PSNR helper (inference/yuv_data.h:11-27): planar 4:2:0
+ * 8-bit files, luma only, whole-clip and per-frame PSNR, reconstruction writer.
+ */
+#ifndef QCNN_YUV_DATA_H
+#define QCNN_YUV_DATA_H
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mat.h"
+
+class vrcnn_data {
+public:
+    vrcnn_data(int frame, int height, int width);
+    int read_data(char *orifile, char *inputfile);          /* inference/yuv_data.cpp:15-42 */
+    int read_frame(char *orifile, char *inputfile, int n);  /* inference/yuv_data.cpp:44-66 */
+    double psnr(datatype *data);                            /* inference/yuv_data.cpp:87-97 */
+    double psnr_pf(void);                                   /* inference/yuv_data.cpp:98-112 */
+    double psnr_frame(const datatype *data, int n);         /* PSNR of frame n of `data` */
+    int save_recon_as(char *filename);                      /* inference/yuv_data.cpp:113-128 */
+    ~vrcnn_data(void);
+
+    int frame, h, w;
+    long nSize;
+    datatype *ori, *input, *recon;
+};
+
+#endif

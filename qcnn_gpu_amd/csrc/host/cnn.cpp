@@ -1,0 +1,301 @@
+// Layer classes of the reference (inference/cnn.cuh) over the C ABI: host C++ only, no HIP headers.
+#include "cnn.h"
+
+#include <string.h>
+
+static int unsupported(const char *what)
+{
+    printf("%s: only the static-quantised (blu) path is implemented\n", what);
+    return QCNN_E_UNSUPPORTED;
+}
+static inline int pad4(int c) { return (c + 3) / 4 * 4; }
+
+// ---------------------------------------------------------------------------------------------
+CovLayer::CovLayer()
+    : batch(0), height(0), width(0), inChannel(0), outChannel(0), ksize(0), wSize(0), uSize(0), vSize(0),
+      workspaceSize(0), max_u(0), step_w(0), step_y(0), blu(0), mul(0), shift(0), w(nullptr), b(nullptr),
+      b_adj(nullptr), u(nullptr), v(nullptr), owns_(false)
+{
+}
+
+static void set_shape(CovLayer *l, int batch, int height, int width, int inChannel, int outChannel, int ksize)
+{
+    l->batch = batch;
+    l->height = height;
+    l->width = width;
+    l->inChannel = inChannel;
+    l->outChannel = outChannel;
+    l->ksize = ksize;
+    l->uSize = batch * outChannel * height * width;
+    l->wSize = ksize * ksize * pad4(inChannel) * outChannel;   // inference/cnn.cu:24
+    l->vSize = batch * pad4(outChannel) * height * width;      // inference/cnn.cu:25
+    l->uDesc = {batch, outChannel, height, width};
+    l->vDesc = {batch, pad4(outChannel), height, width};
+    l->workspaceSize = 0;                                      // the direct convolution needs no workspace
+}
+
+int CovLayer::build(qcnnHandle_t, qcnnTensorDescriptor_t, int batch, int height, int width, int inChannel,
+                    int outChannel, int ksize)
+{
+    set_shape(this, batch, height, width, inChannel, outChannel, ksize);
+    check(qcnn_dev_alloc(&w, sizeof(xwtype) * (size_t)wSize));
+    check(qcnn_dev_alloc(&b, sizeof(btype) * (size_t)outChannel));
+    check(qcnn_dev_alloc(&b_adj, sizeof(btype) * (size_t)outChannel));
+    check(qcnn_dev_alloc(&u, sizeof(convtype) * (size_t)uSize));
+    check(qcnn_dev_alloc(&v, sizeof(xwtype) * (size_t)vSize));
+    owns_ = true;
+    return 0;
+}
+
+int CovLayer::adopt(int batch, int height, int width, int inChannel, int outChannel, int ksize, void *w_, void *b_,
+                    void *u_, void *v_)
+{
+    set_shape(this, batch, height, width, inChannel, outChannel, ksize);
+    w = w_;
+    b = b_;
+    u = u_;
+    v = v_;
+    owns_ = false;
+    return 0;
+}
+
+int CovLayer::load_static_para(FILE *fp)
+{
+    xwtype *w_h = (xwtype *)malloc(sizeof(xwtype) * (size_t)wSize);
+    btype *b_h = (btype *)malloc(sizeof(btype) * (size_t)outChannel);
+    int *b_int = (int *)malloc(sizeof(int) * (size_t)outChannel);
+    size_t ok = fread(w_h, sizeof(xwtype), (size_t)wSize, fp) == (size_t)wSize;
+    ok &= fread(b_int, sizeof(int), (size_t)outChannel, fp) == (size_t)outChannel;
+    ok &= fread(&blu, sizeof(int), 1, fp) == 1;
+    ok &= fread(&mul, sizeof(int), 1, fp) == 1;
+    ok &= fread(&shift, sizeof(int), 1, fp) == 1;
+    if (!ok) {
+        printf("model file is too short.\n");
+        exit(1);
+    }
+    for (int i = 0; i < outChannel; i++) b_h[i] = (btype)b_int[i];  // inference/cnn.cu:104
+    if (owns_) {  // adopted layers get their parameters through the engine's own loader
+        check(qcnn_dev_h2d(w, w_h, sizeof(xwtype) * (size_t)wSize));
+        check(qcnn_dev_h2d(b, b_h, sizeof(btype) * (size_t)outChannel));
+    }
+    free(w_h);
+    free(b_h);
+    free(b_int);
+    return 0;
+}
+
+int CovLayer::ConvForward_static(qcnnHandle_t handle, qcnnTensorDescriptor_t, void *x, void *, size_t)
+{
+    check(qcnn_op_conv_static(x, w, b, u, height, width, inChannel, outChannel, ksize, handle ? handle->stream : nullptr));
+    return 0;
+}
+
+int CovLayer::quantize_out_blu(void)
+{
+    return NCHW2NCHW_VECT_C_QUANT_BLU((convtype *)u, (xwtype *)v, batch, outChannel, height, width, blu, mul, shift);
+}
+
+int CovLayer::viewmem(xwtype *x)
+{
+    // the 5x5 corner dump of inference/cnn.cu:203-248
+    const size_t hw = (size_t)height * width;
+    xwtype *x_h = new xwtype[hw * 4];
+    convtype *u_h = new convtype[hw];
+    xwtype *v_h = new xwtype[hw * 4];
+    xwtype w_h[20];
+    btype b_h[1];
+    check(qcnn_dev_sync());
+    check(qcnn_dev_d2h(x_h, x, hw * 4));
+    check(qcnn_dev_d2h(w_h, w, sizeof w_h < (size_t)wSize ? sizeof w_h : (size_t)wSize));
+    check(qcnn_dev_d2h(u_h, u, sizeof(convtype) * hw));
+    check(qcnn_dev_d2h(v_h, v, hw * 4));
+    check(qcnn_dev_d2h(b_h, b, sizeof b_h));
+    const int n = height < 5 ? height : 5, m = width < 5 ? width : 5;
+    printf("x:\n");
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < m; j++) printf("%d\t", x_h[(i * width + j) * 4]);
+        printf("\n");
+    }
+    printf("weights:\n");
+    for (int i = 0; i < 5 && i * 4 < wSize; i++) printf("%d\t", w_h[i * 4]);
+    printf("\nbiases:%f\n", b_h[0]);
+    printf("u:\n");
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < m; j++) printf("%f\t", u_h[i * width + j]);
+        printf("\n");
+    }
+    printf("mul:%d,shift:%d\n", mul, shift);
+    printf("v:\n");
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < m; j++) printf("%d\t", v_h[(i * width + j) * 4]);
+        printf("\n");
+    }
+    delete[] x_h;
+    delete[] u_h;
+    delete[] v_h;
+    return 0;
+}
+
+int CovLayer::load_para(FILE *) { check(unsupported("CovLayer::load_para")); return 0; }
+int CovLayer::ConvForward(qcnnHandle_t, qcnnTensorDescriptor_t, void *, void *, size_t)
+{
+    check(unsupported("CovLayer::ConvForward"));
+    return 0;
+}
+int CovLayer::activate(qcnnHandle_t) { check(unsupported("CovLayer::activate")); return 0; }
+int CovLayer::quantize_out(void *) { check(unsupported("CovLayer::quantize_out")); return 0; }
+int CovLayer::quantize_out_fix(int) { check(unsupported("CovLayer::quantize_out_fix")); return 0; }
+int CovLayer::quantize_out_static(void) { check(unsupported("CovLayer::quantize_out_static")); return 0; }
+
+CovLayer::~CovLayer()
+{
+    if (owns_) {
+        qcnn_dev_free(w);
+        qcnn_dev_free(b);
+        qcnn_dev_free(b_adj);
+        qcnn_dev_free(u);
+        qcnn_dev_free(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+ConcatLayer::ConcatLayer(void)
+    : batch(0), height(0), width(0), inChannel1(0), inChannel2(0), outChannel(0), conc(nullptr), owns_(false)
+{
+}
+
+int ConcatLayer::build(int batch_, int height_, int width_, int inChannel1_, int inChannel2_)
+{
+    adopt(batch_, height_, width_, inChannel1_, inChannel2_, nullptr);
+    check(qcnn_dev_alloc(&conc, sizeof(xwtype) * (size_t)batch * outChannel * height * width));
+    owns_ = true;
+    return 0;
+}
+
+int ConcatLayer::adopt(int batch_, int height_, int width_, int inChannel1_, int inChannel2_, void *conc_)
+{
+    batch = batch_;
+    height = height_;
+    width = width_;
+    inChannel1 = inChannel1_;
+    inChannel2 = inChannel2_;
+    outChannel = inChannel1_ + inChannel2_;
+    concDesc = {batch, outChannel, height, width};
+    conc = conc_;
+    owns_ = false;
+    return 0;
+}
+
+int ConcatLayer::concat_blu(CovLayer *C1, CovLayer *C2)
+{
+    // host bookkeeping of inference/cnn.cu:378-381 (unused by the static path, kept observable)
+    C1->step_y = ((1 << C1->shift) + C1->mul / 2) / C1->mul;
+    C2->step_y = ((1 << C2->shift) + C2->mul / 2) / C2->mul;
+    C1->max_u = 127 * C1->step_y;
+    C2->max_u = 127 * C2->step_y;
+    const size_t channelSize = (size_t)C1->height * C1->width;
+    const size_t frameSize1 = (size_t)C1->outChannel * channelSize, frameSize2 = (size_t)C2->outChannel * channelSize;
+    const size_t frameSize = frameSize1 + frameSize2;
+    for (int i = 0; i < C1->batch; i++) {
+        check(qcnn_op_quant_blu((convtype *)C1->u + i * frameSize1, (xwtype *)conc + i * frameSize, channelSize,
+                                C1->outChannel, C1->blu, C1->mul, C1->shift, nullptr));
+        check(qcnn_op_quant_blu((convtype *)C2->u + i * frameSize2, (xwtype *)conc + i * frameSize + frameSize1,
+                                channelSize, C2->outChannel, C2->blu, C2->mul, C2->shift, nullptr));
+    }
+    return 0;
+}
+
+int ConcatLayer::concat(CovLayer *, CovLayer *, void *) { check(unsupported("ConcatLayer::concat")); return 0; }
+
+ConcatLayer::~ConcatLayer()
+{
+    if (owns_) qcnn_dev_free(conc);
+}
+
+// ---------------------------------------------------------------------------------------------
+InputLayer::InputLayer(void)
+    : batch(0), height(0), width(0), inChannel(0), outChannel(0), inSize(0), outSize(0), x(nullptr), x_ppro(nullptr),
+      x_rec(nullptr), owns_(false)
+{
+}
+
+int InputLayer::adopt(int batch_, int channel, int height_, int width_, void *x_, void *x_ppro_, void *x_rec_)
+{
+    batch = batch_;
+    height = height_;
+    width = width_;
+    inChannel = channel;
+    inSize = batch * height * width * channel;
+    outChannel = pad4(channel);                  // XWTYPE == INT8x4, inference/cnn.cu:421-425
+    outSize = batch * height * width * outChannel;
+    xDesc = {batch, outChannel, height, width};
+    x = x_;
+    x_ppro = x_ppro_;
+    x_rec = x_rec_;
+    owns_ = false;
+    return 0;
+}
+
+int InputLayer::build(int batch_, int channel, int height_, int width_)
+{
+    adopt(batch_, channel, height_, width_, nullptr, nullptr, nullptr);
+    check(qcnn_dev_alloc(&x, sizeof(datatype) * (size_t)inSize));
+    check(qcnn_dev_alloc(&x_rec, sizeof(datatype) * (size_t)inSize));
+    check(qcnn_dev_alloc(&x_ppro, sizeof(xwtype) * (size_t)outSize));
+    check(qcnn_dev_memset(x_ppro, 0, sizeof(xwtype) * (size_t)outSize));
+    owns_ = true;
+    return 0;
+}
+
+int InputLayer::load(datatype *input)
+{
+    check(qcnn_dev_h2d(x, input, sizeof(datatype) * (size_t)batch * inChannel * height * width));
+    return 0;
+}
+
+int InputLayer::ppro(void)
+{
+    // one launch per (batch, channel) plane as inference/cnn.cu:460-466; channel c lands in lane c&3
+    // of vec4 group c>>2.  With CHANNEL == 1 this is a single launch that also zeroes lanes 1..3.
+    if (inChannel != 1) check(unsupported("InputLayer::ppro with more than one channel"));
+    for (int i = 0; i < batch; i++)
+        check(qcnn_op_ppro((datatype *)x + (size_t)i * height * width, (xwtype *)x_ppro + (size_t)i * height * width * 4,
+                           (size_t)height * width, nullptr));
+    return 0;
+}
+
+int InputLayer::applyRes_y(convtype *res, int mul, int shift)
+{
+    check(qcnn_op_apply_res_y(x, x_rec, res, mul, shift, (size_t)inSize, nullptr));
+    return 0;
+}
+
+int InputLayer::applyRes(xwtype *) { check(unsupported("InputLayer::applyRes")); return 0; }
+
+InputLayer::~InputLayer(void)
+{
+    if (owns_) {
+        qcnn_dev_free(x);
+        qcnn_dev_free(x_ppro);
+        qcnn_dev_free(x_rec);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+char *HWCN2NCHW_VECT_C_CPU(char *HWCN, int H, int W, int C, int N, int *outSize)
+{
+    *outSize = N * ((C + 3) / 4) * H * W * 4;
+    char *out = new char[*outSize];
+    qcnn_hwcn2nchw_vect_c((const int8_t *)HWCN, H, W, C, N, (int8_t *)out);
+    return out;
+}
+
+int NCHW2NCHW_VECT_C_QUANT_BLU(convtype *before, xwtype *after, int N, int C, int H, int W, int blu, int multiplier,
+                               int shifts)
+{
+    const size_t frameSize = (size_t)C * H * W;
+    for (int i = 0; i < N; i++)
+        check(qcnn_op_quant_blu(before + i * frameSize, after + i * frameSize, (size_t)H * W, C, blu, multiplier, shifts,
+                                nullptr));
+    return 0;
+}

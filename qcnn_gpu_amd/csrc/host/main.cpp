@@ -1,0 +1,168 @@
+// QCNN_GPU: the reference's driver program (inference/kernel.cu:74-138) for Linux / MI355X.
+//
+//   QCNN_GPU <ori.yuv> <anchor_prefix> <height> <width>
+//
+// Same positional arguments, stdout lines, log.txt record and recon_psnr.data double as the
+// reference.  What the reference fixes at compile time is read from the environment:
+//   QCNN_MODEL   printf pattern of the model file, %d = QP
+//                (default "qvrcnn_nchw_vect_c_8bit_qfp_%d.data"; inference/kernel.cu:7)
+//   QCNN_QPS     comma list of QPs (default "22": the loop bounds of inference/kernel.cu:122)
+//   QCNN_FRAMES  frames per sequence (default 1 = FRAME, inference/mat.cuh:23)
+//   QCNN_GPUS    number of GPUs to shard frames over (default 1; frame i -> GPU i mod G)
+//   QCNN_PSNR_PF=1     also print "PSNR of Frame %d:%f" per frame (inference/yuv_data.cpp:109)
+//   QCNN_SAVE_RECON=f  write the reconstruction as YUV 4:2:0 (inference/yuv_data.cpp:113-128)
+//   QCNN_CONVERT=1     run convert_model() instead (inference/kernel.cu:17-26): HWCN -> NCHW_VECT_C,
+//                      input pattern QCNN_MODEL_HWCN (default "qvrcnn_hwcn_8bit_qfp_%d.data")
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <time.h>
+
+#include "qvrcnn.h"
+#include "yuv_data.h"
+
+static const char *env_or(const char *name, const char *dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? v : dflt;
+}
+
+static std::vector<int> parse_qps(const char *s)
+{
+    std::vector<int> out;
+    std::string cur;
+    for (const char *p = s;; ++p) {
+        if (*p == ',' || *p == 0) {
+            if (!cur.empty()) out.push_back(atoi(cur.c_str()));
+            cur.clear();
+            if (!*p) break;
+        } else
+            cur.push_back(*p);
+    }
+    return out;
+}
+
+// One worker per GPU: the frame loop of inference/kernel.cu:91-97 over frames g, g+G, g+2G, ...
+static void worker(int gpu, int ngpu, char *model_fn, vrcnn_data *d, int frame, int channel, int height, int width)
+{
+    qvrcnn net(gpu, 1, channel, height, width);
+    net.load_static_para(model_fn);
+    const long fs = (long)channel * height * width;
+    for (int i = gpu; i < frame; i += ngpu) {
+        net.load_data(d->input + i * fs);
+        net.forward_blu();
+        check(qcnn_sync(net.engine));
+        check(qcnn_dev_d2h(d->recon + i * fs, net.I1.x_rec, (size_t)fs));
+    }
+}
+
+// stdout line, log.txt record and recon_psnr.data double of inference/kernel.cu:105-115
+static void report(vrcnn_data &d, char *input_fn, int frame, int height, int width, long long us)
+{
+    time_t now = time(0);
+    if (getenv("QCNN_PSNR_PF")) d.psnr_pf();
+    const double psnr1 = d.psnr(d.input);
+    const double psnr2 = d.psnr(d.recon);
+    printf("\nbefore net:PSNR=%.3f\nafter quantized net:PSNR=%.3f\ntime:%lldus\n", psnr1, psnr2, us);
+    FILE *logfile = fopen("log.txt", "a+");
+    if (!logfile)
+        printf("write file failed\n");
+    else {
+        fprintf(logfile,
+                "\nQVRCNN test date:%sdata:%s\nframes:%d\nheight:%d\nwidth:%d\nbefore net:PSNR=%f\nafter quantized "
+                "net:PSNR=%f\ntime:%lldus\n",
+                ctime(&now), input_fn, frame, height, width, psnr1, psnr2, us);
+        fclose(logfile);
+    }
+    logfile = fopen("recon_psnr.data", "ab+");
+    if (!logfile)
+        printf("open psnr file failed\n");
+    else {
+        fwrite(&psnr2, sizeof(double), 1, logfile);
+        fclose(logfile);
+    }
+    if (getenv("QCNN_SAVE_RECON")) d.save_recon_as(getenv("QCNN_SAVE_RECON"));
+}
+
+static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, int channel, int height, int width,
+                       int ngpu)
+{
+    vrcnn_data test_data(frame, height, width);
+    long long us;
+    if (ngpu <= 1) {
+        // set-up and model load happen before the clock starts, as in inference/kernel.cu:86-90;
+        // the engine is kept across QPs (models switch by reloading, no rebuild)
+        static qvrcnn *cached = nullptr;
+        static int ch = 0, cw = 0;
+        if (!cached || ch != height || cw != width) {
+            delete cached;
+            cached = new qvrcnn(0, 1, channel, height, width);
+            ch = height;
+            cw = width;
+        }
+        cached->load_static_para(model_fn);
+        test_data.read_data(ori_fn, input_fn);
+        const long fs = (long)channel * height * width;
+        const auto t1 = std::chrono::steady_clock::now();
+        for (int i = 0; i < frame; i++) {
+            cached->load_data(test_data.input + i * fs);
+            cached->forward_blu();
+            check(qcnn_sync(cached->engine));
+            check(qcnn_dev_d2h(test_data.recon + i * fs, cached->I1.x_rec, (size_t)fs));
+        }
+        us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+    } else {
+        // whole frames sharded round-robin, one host thread and one engine per GPU, no communication
+        // between GPUs; here the clock includes engine set-up and model load on every GPU
+        test_data.read_data(ori_fn, input_fn);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (int g = 0; g < ngpu; ++g)
+            th.emplace_back(worker, g, ngpu, model_fn, &test_data, frame, channel, height, width);
+        for (auto &t : th) t.join();
+        us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+    }
+    report(test_data, input_fn, frame, height, width, us);
+}
+
+static int run_all(char *oriname, char *inputname, int height, int width)
+{
+    const std::vector<int> qps = parse_qps(env_or("QCNN_QPS", "22"));
+    const char *pattern = env_or("QCNN_MODEL", "qvrcnn_nchw_vect_c_8bit_qfp_%d.data");
+    const int frames = atoi(env_or("QCNN_FRAMES", "1"));
+    int ngpu = atoi(env_or("QCNN_GPUS", "1"));
+    int have = 0;
+    check(qcnn_device_count(&have));
+    if (ngpu > have) ngpu = have;
+    char input_fn[1024], model_fn[1024];
+    for (int qp : qps) {
+        snprintf(input_fn, sizeof input_fn, "%sQ%d.yuv", inputname, qp);  // inference/kernel.cu:124
+        snprintf(model_fn, sizeof model_fn, pattern, qp);                 // inference/kernel.cu:125
+        testqvrcnn(oriname, input_fn, model_fn, frames > 0 ? frames : 1, CHANNEL, height, width, ngpu);
+        check(qcnn_dev_sync());
+    }
+    return 0;
+}
+
+static void convert_model(void)
+{
+    const std::vector<int> qps = parse_qps(env_or("QCNN_QPS", "32"));  // inference/kernel.cu:20
+    for (int qp : qps)
+        model_qfp_HWCN2NCHW_VECT_C(env_or("QCNN_MODEL_HWCN", "qvrcnn_hwcn_8bit_qfp_%d.data"),
+                                   env_or("QCNN_MODEL", "qvrcnn_nchw_vect_c_8bit_qfp_%d.data"), qp);
+}
+
+int main(int argc, char **argv)
+{
+    if (getenv("QCNN_CONVERT")) {
+        convert_model();
+        return 0;
+    }
+    if (argc < 5) {
+        printf("usage: %s <ori.yuv> <anchor_prefix> <height> <width>\n", argv[0]);
+        return 1;
+    }
+    return run_all(argv[1], argv[2], atoi(argv[3]), atoi(argv[4]));
+}

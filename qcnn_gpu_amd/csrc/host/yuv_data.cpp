@@ -1,0 +1,125 @@
+// vrcnn_data of the reference (inference/yuv_data.cpp): YUV 4:2:0 luma reader, PSNR, recon writer.
+#include "yuv_data.h"
+
+vrcnn_data::vrcnn_data(int frame, int height, int width)
+{
+    this->frame = frame;
+    this->h = height;
+    this->w = width;
+    this->nSize = (long)frame * height * width;
+    this->ori = new datatype[nSize];
+    this->input = new datatype[nSize];
+    this->recon = new datatype[nSize];
+}
+
+int vrcnn_data::read_data(char *orifile, char *inputfile)
+{
+    FILE *orifp = fopen(orifile, "rb"), *inputfp;
+    if (!orifp) {
+        printf("%s\n", orifile);
+        printf("open ori file failed\n");
+        exit(1);
+    }
+    inputfp = fopen(inputfile, "rb");
+    if (!inputfp) {
+        printf("%s\n", inputfile);
+        printf("open input file failed\n");
+        fclose(orifp);
+        exit(1);
+    }
+    const long hw = (long)h * w;
+    for (int i = 0; i < frame; ++i) {
+        // luma, then skip the h*w/2 chroma bytes (inference/yuv_data.cpp:34-37)
+        if (fread(ori + i * hw, sizeof(datatype), hw, orifp) != (size_t)hw ||
+            fread(input + i * hw, sizeof(datatype), hw, inputfp) != (size_t)hw) {
+            printf("short read at frame %d\n", i);
+            exit(1);
+        }
+        fseek(orifp, sizeof(datatype) * hw / 2, SEEK_CUR);
+        fseek(inputfp, sizeof(datatype) * hw / 2, SEEK_CUR);
+    }
+    fclose(orifp);
+    fclose(inputfp);
+    return 0;
+}
+
+int vrcnn_data::read_frame(char *orifile, char *inputfile, int n)
+{
+    FILE *orifp = fopen(orifile, "rb"), *inputfp;
+    frame = 1;
+    if (!orifp) {
+        printf("open file failed\n");
+        return 1;
+    }
+    inputfp = fopen(inputfile, "rb");
+    if (!inputfp) {
+        printf("open file failed\n");
+        fclose(orifp);
+        return 1;
+    }
+    const long hw = (long)h * w;
+    fseek(orifp, sizeof(datatype) * hw * n * 3 / 2, SEEK_CUR);
+    size_t got = fread(ori, sizeof(datatype), hw, orifp);
+    fseek(inputfp, sizeof(datatype) * hw * n * 3 / 2, SEEK_CUR);
+    got += fread(input, sizeof(datatype), hw, inputfp);
+    fclose(orifp);
+    fclose(inputfp);
+    return got == (size_t)(2 * hw) ? 0 : 1;
+}
+
+static double psnr_of(const datatype *data, const datatype *ori, long n)
+{
+    // inference/yuv_data.cpp:91-95; integer accumulation gives the same double (sums < 2^53)
+    unsigned long long sse = 0;
+    for (long i = 0; i < n; i++) {
+        const int d = (int)data[i] - (int)ori[i];
+        sse += (unsigned)(d * d);
+    }
+    double mse = (double)sse;
+    mse /= (double)n;
+    return 10 * log10(65025.0 / mse);
+}
+
+double vrcnn_data::psnr(datatype *data) { return psnr_of(data, ori, nSize); }
+
+double vrcnn_data::psnr_frame(const datatype *data, int n)
+{
+    const long hw = (long)h * w;
+    return psnr_of(data + n * hw, ori + n * hw, hw);
+}
+
+double vrcnn_data::psnr_pf(void)
+{
+    double p = 0;
+    for (int n = 0; n < frame; n++) {
+        p = psnr_frame(recon, n);
+        printf("PSNR of Frame %d:%f\n", n, p);  // inference/yuv_data.cpp:109
+    }
+    return p;
+}
+
+int vrcnn_data::save_recon_as(char *filename)
+{
+    FILE *fp = fopen(filename, "wb");
+    if (!fp) {
+        printf("write file failed\n");
+        return 1;
+    }
+    const long hw = (long)h * w;
+    datatype *uv = new datatype[hw / 2];
+    memset(uv, 0, hw / 2);
+    for (int i = 0; i < frame; i++) {
+        fwrite(recon + i * hw, sizeof(datatype), hw, fp);
+        fwrite(uv, sizeof(datatype), hw / 2, fp);
+    }
+    delete[] uv;
+    fclose(fp);
+    return 0;
+}
+
+vrcnn_data::~vrcnn_data(void)
+{
+    delete[] ori;
+    delete[] input;
+    delete[] recon;
+}

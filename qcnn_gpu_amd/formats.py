@@ -12,6 +12,7 @@
 """
 from __future__ import annotations
 
+import math
 import pickletools
 import struct
 import time
@@ -306,4 +307,4 @@ def psnr_from_sse(sse: int, n: int) -> float:
     mse = float(sse) / float(n)
     if mse == 0.0:
         return float("inf")
-    return 10.0 * float(np.log10(65025.0 / mse))
+    return 10 * math.log10(65025.0 / mse)  # the C library's log10, as the reference calls it

@@ -1,0 +1,120 @@
+"""The QCNN_GPU driver program and the reference-shaped C++ API, run as the reference's harness runs
+them (positional argv, log.txt, recon_psnr.data), against the oracle.  Bit-exact / last decimal."""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from qcnn_gpu_amd import formats, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "qcnn_gpu_amd", "bin", "QCNN_GPU")
+FACADE = os.path.join(ROOT, "qcnn_gpu_amd", "bin", "facade_check")
+
+
+def _write_case(tmp, h, w, qps, frames=1):
+    ori = None
+    for qp in qps:
+        o, a = synth.synth_frames(h, w, qp, frames=frames, seed=77)
+        if ori is None:
+            ori = synth.synth_frames(h, w, qps[0], frames=frames, seed=77)[0]
+            formats.write_yuv420_luma(str(tmp / "seq.yuv"), ori, chroma_value=128)
+        # anchors of every QP are degraded versions of the same original
+        a = np.clip(ori.astype(np.int16) + (a.astype(np.int16) - o.astype(np.int16)), 0, 255).astype(np.uint8)
+        formats.write_yuv420_luma(str(tmp / f"anchor_Q{qp}.yuv"), a, chroma_value=77)
+        with open(tmp / f"model_{qp}.data", "wb") as f:
+            f.write(synth.synth_model(qp).to_nchw_vect_c_bytes())
+    return ori
+
+
+def _run(tmp, h, w, env):
+    e = dict(os.environ, QCNN_MODEL=str(tmp / "model_%d.data"), **env)
+    return subprocess.run([EXE, str(tmp / "seq.yuv"), str(tmp / "anchor_"), str(h), str(w)], cwd=tmp, env=e,
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_driver_single_qp_outputs(tmp_path):
+    h, w, qp = 240, 416, 37
+    ori = _write_case(tmp_path, h, w, [qp])
+    r = _run(tmp_path, h, w, {"QCNN_QPS": str(qp), "QCNN_SAVE_RECON": "recon.yuv", "QCNN_PSNR_PF": "1"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    anc = formats.read_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), 1, h, w)
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    rec_o = c_oracle.forward_blu(mb, anc[0])
+    p1, p2 = c_oracle.psnr(anc[0], ori[0]), c_oracle.psnr(rec_o, ori[0])
+    m = re.search(r"\nbefore net:PSNR=([\d.]+)\nafter quantized net:PSNR=([\d.]+)\ntime:(\d+)us\n", r.stdout)
+    assert m, r.stdout
+    assert m.group(1) == "%.3f" % p1 and m.group(2) == "%.3f" % p2          # last printed decimal
+    assert ("PSNR of Frame 0:%f" % p2) in r.stdout
+    # recon_psnr.data: one raw double, identical bits
+    raw = (tmp_path / "recon_psnr.data").read_bytes()
+    assert raw == struct.pack("<d", p2)
+    # log.txt record
+    log = (tmp_path / "log.txt").read_text()
+    assert log.startswith("\nQVRCNN test date:")
+    assert ("data:%s\nframes:1\nheight:%d\nwidth:%d\nbefore net:PSNR=%f\nafter quantized net:PSNR=%f\ntime:%sus\n"
+            % (str(tmp_path / f"anchor_Q{qp}.yuv"), h, w, p1, p2, m.group(3))) in log
+    # reconstruction file: luma bit-exact, chroma zero-filled
+    rec = formats.read_yuv420_luma(str(tmp_path / "recon.yuv"), 1, h, w)
+    assert np.array_equal(rec[0], rec_o)
+    assert (tmp_path / "recon.yuv").stat().st_size == h * w * 3 // 2
+
+
+def test_driver_four_qps_and_frames_in_one_process(tmp_path):
+    """configs[2] at the process level: QP 22,27,32,37 back to back, 3 frames each, appended outputs."""
+    h, w, qps, frames = 96, 160, [22, 27, 32, 37], 3
+    ori = _write_case(tmp_path, h, w, qps, frames)
+    r = _run(tmp_path, h, w, {"QCNN_QPS": "22,27,32,37", "QCNN_FRAMES": str(frames)})
+    assert r.returncode == 0, r.stdout + r.stderr
+    doubles = formats.read_psnr_doubles(str(tmp_path / "recon_psnr.data"))
+    assert doubles.shape == (4,)
+    for i, qp in enumerate(qps):
+        anc = formats.read_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), frames, h, w)
+        mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+        rec = np.stack([c_oracle.forward_blu(mb, anc[f]) for f in range(frames)])
+        assert doubles[i] == c_oracle.psnr(rec, ori)             # whole-clip PSNR, identical double
+    assert (tmp_path / "log.txt").read_text().count("QVRCNN test date:") == 4
+
+
+def test_driver_errors_like_the_reference(tmp_path):
+    _write_case(tmp_path, 32, 32, [37])
+    r = _run(tmp_path, 32, 32, {"QCNN_QPS": "27"})                # no model / anchor for QP27
+    assert r.returncode == 1 and "cannot open model file." in r.stdout
+    e = dict(os.environ, QCNN_MODEL=str(tmp_path / "model_%d.data"), QCNN_QPS="37")
+    r = subprocess.run([EXE, str(tmp_path / "missing.yuv"), str(tmp_path / "anchor_"), "32", "32"], cwd=tmp_path,
+                       env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "open ori file failed" in r.stdout
+
+
+def test_driver_model_conversion(tmp_path):
+    m = synth.synth_model(32)
+    (tmp_path / "hwcn_32.data").write_bytes(m.to_hwcn_bytes())
+    e = dict(os.environ, QCNN_CONVERT="1", QCNN_QPS="32", QCNN_MODEL_HWCN=str(tmp_path / "hwcn_%d.data"),
+             QCNN_MODEL=str(tmp_path / "vect_%d.data"))
+    r = subprocess.run([EXE], cwd=tmp_path, env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "vect_32.data").read_bytes() == m.to_nchw_vect_c_bytes()
+
+
+def test_cpp_layer_api_matches_oracle(tmp_path):
+    h, w, qp = 50, 70, 27
+    ori = _write_case(tmp_path, h, w, [qp])
+    out = tmp_path / "out"
+    r = subprocess.run([FACADE, str(tmp_path / f"model_{qp}.data"), str(tmp_path / "seq.yuv"),
+                        str(tmp_path / f"anchor_Q{qp}.yuv"), str(h), str(w), str(out)],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, FACADE_VIEWMEM="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    anc = formats.read_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), 1, h, w)
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    rec_o, taps = c_oracle.forward_blu(mb, anc[0], True)
+    assert np.array_equal(np.fromfile(str(out) + ".fused", np.uint8).reshape(h, w), rec_o)
+    assert np.array_equal(np.fromfile(str(out) + ".layers", np.uint8).reshape(h, w), rec_o)
+    assert np.array_equal(np.fromfile(str(out) + ".c1v", np.int8).reshape(16, h, w, 4), taps["v1"])
+    t = synth.QUANT_TRIPLES[qp]
+    assert f"C1 blu={t[0][0]} mul={t[0][1]} shift={t[0][2]}  C4 mul={t[5][1]} shift={t[5][2]}" in r.stdout
+    assert "mul:%d,shift:%d" % (t[0][1], t[0][2]) in r.stdout      # viewmem dump, inference/cnn.cu:235
