@@ -45,10 +45,11 @@ namespace kb {
 constexpr int TH = 18, TW = 30;
 constexpr int C3R = TH + 2, C3C = 32;   // C3 output region held in LDS (halo 1)
 constexpr int INR = TH + 4, INC = 34;   // conc1 input region (halo 2)
-constexpr int PX = 48;                  // bytes per pixel of conc1 / conc2 images
-constexpr int SIN_BYTES = INR * INC * PX;
+constexpr int PX = 48;                  // bytes per pixel of the conc2 tile (and of conc1 in HBM)
+constexpr int SIN_BYTES = INR * INC * 64;        // conc1 tile: 64-byte pixels, rotated chunks
 constexpr int SC3_BYTES = C3R * C3C * PX + 256;  // + slack: edge lanes read 2 pixels past a row
-constexpr int LDS_BYTES = SIN_BYTES + SC3_BYTES;
+constexpr int LDS_BYTES = 2 * SIN_BYTES + 2 * SC3_BYTES;  // both tiles double-buffered
+static_assert(LDS_BYTES <= 160 * 1024, "kernel B exceeds the 160 KiB of LDS of one CU");
 }  // namespace kb
 
 // Offsets (bytes) of the packed MFMA A-operand fragments inside one device buffer.
