@@ -77,6 +77,12 @@ int qcnn_forward_blu(qcnn_t *e);
  * i*stride (stride in bytes, >= height*width).  Asynchronous on the engine stream. */
 int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride);
 
+/* Frames that one kernel launch of qcnn_forward_blu_batch covers (the loop of
+ * inference/kernel.cu:91-97 has no such knob: it is the price of the intermediate conc1 image,
+ * 48*height*width bytes of device scratch per frame of a launch).  set > 0 changes it, current
+ * (may be NULL) receives the value in force.  Default: as many frames as fit 2 GiB, at most 16. */
+int qcnn_batch_group(qcnn_t *e, int set, int *current);
+
 /* The same pass run layer by layer through the qcnn_op_* kernels below, materialising every
  * buffer of the reference (x_ppro, u, v, conc) in the reference's layouts: the tap/debug mode
  * (the role of MEM_DBG / viewmem, inference/cnn.cu:203-248). */

@@ -58,7 +58,9 @@ struct qcnn_engine {
     const uint8_t *bound_y = nullptr;
     uint8_t *bound_rec = nullptr;
     // fused path
-    int8_t *conc1_int = nullptr;  // [H][W][48]
+    int8_t *conc1_int = nullptr;  // [conc_frames][H][W][48]
+    int conc_frames = 0;          // capacity of conc1_int, in frames
+    int group = 1;                // frames per kernel launch of forward_blu_batch
     int8_t *wpack = nullptr;
     int *bias_i = nullptr;
     float *bias_f = nullptr;
@@ -238,11 +240,28 @@ static int load_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
     return QCNN_OK;
 }
 
-static FusedArgs fused_args(qcnn_engine *e)
+// conc1 scratch for `frames` frames per launch (grown on demand, never shrunk)
+static int ensure_conc(qcnn_engine *e, int frames)
+{
+    if (frames <= e->conc_frames) return QCNN_OK;
+    HIP_TRY(hipSetDevice(e->gpu));
+    if (e->stream) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->conc1_int) HIP_TRY(hipFree(e->conc1_int));
+    e->conc1_int = nullptr;
+    e->conc_frames = 0;
+    HIP_TRY(hipMalloc(&e->conc1_int, (size_t)frames * 48 * e->HW));
+    e->conc_frames = frames;
+    return QCNN_OK;
+}
+
+static FusedArgs fused_args(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nframes, size_t stride)
 {
     FusedArgs a;
-    a.y = e->bound_y ? e->bound_y : e->x;
-    a.rec = e->bound_rec ? e->bound_rec : e->x_rec;
+    a.y = y;
+    a.rec = rec;
+    a.nframes = nframes;
+    a.frame_stride = stride;
+    a.conc_stride = 48 * e->HW;
     a.conc1 = e->conc1_int;
     a.wpack = e->wpack;
     a.bias_i = e->bias_i;
@@ -309,6 +328,14 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY_E(hipMalloc(&e->x, e->HW));
     HIP_TRY_E(hipMalloc(&e->x_rec, e->HW));
     HIP_TRY_E(hipMalloc(&e->conc1_int, 48 * e->HW));
+    e->conc_frames = 1;
+    {
+        // frames per launch of the batch entry point: as many as fit a scratch budget (default 2 GiB)
+        const char *gb = getenv("QCNN_BATCH_GROUP");
+        const long long fit = (2ll << 30) / (long long)(48 * e->HW);
+        e->group = gb ? atoi(gb) : (int)(fit < 1 ? 1 : fit > 16 ? 16 : fit);
+        if (e->group < 1) e->group = 1;
+    }
     HIP_TRY_E(hipMalloc(&e->wpack, PackedOffsets::TOTAL));
     HIP_TRY_E(hipMalloc(&e->bias_i, 161 * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->bias_f, 161 * sizeof(float)));
@@ -397,12 +424,11 @@ int qcnn_upload_async(qcnn_t *e, const uint8_t *host_y)
     return QCNN_OK;
 }
 
-int qcnn_forward_blu(qcnn_t *e)
+// one launch of each fused kernel over `nframes` frames (nframes <= capacity of the conc1 scratch)
+static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nframes, size_t stride)
 {
-    if (!e) return fail(QCNN_E_ARG, "null engine");
-    if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
     HIP_TRY(hipSetDevice(e->gpu));
-    const FusedArgs a = fused_args(e);
+    const FusedArgs a = fused_args(e, y, rec, nframes, stride);
     hipEvent_t *ev = nullptr;
     if (e->timing) {
         if (e->ev_used + 3 > e->ev.size()) {
@@ -425,21 +451,40 @@ int qcnn_forward_blu(qcnn_t *e)
     return QCNN_OK;
 }
 
+int qcnn_forward_blu(qcnn_t *e)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
+    return launch_frames(e, e->bound_y ? e->bound_y : e->x, e->bound_rec ? e->bound_rec : e->x_rec, 1, e->HW);
+}
+
 int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride)
 {
     if (!e || !dev_y || !dev_rec) return fail(QCNN_E_ARG, "null argument");
+    if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
     if (nframes < 0 || stride < e->HW) return fail(QCNN_E_ARG, "bad batch: nframes=%d stride=%zu", nframes, stride);
-    const uint8_t *keep_y = e->bound_y;
-    uint8_t *keep_rec = e->bound_rec;
-    int rc = QCNN_OK;
-    for (int i = 0; i < nframes && rc == QCNN_OK; ++i) {
-        e->bound_y = static_cast<const uint8_t *>(dev_y) + (size_t)i * stride;
-        e->bound_rec = static_cast<uint8_t *>(dev_rec) + (size_t)i * stride;
-        rc = qcnn_forward_blu(e);
+    const int group = nframes < e->group ? nframes : e->group;
+    if (group > 0) {
+        const int rc = ensure_conc(e, group);
+        if (rc) return rc;
     }
-    e->bound_y = keep_y;
-    e->bound_rec = keep_rec;
-    return rc;
+    // the persistent kernels walk the tiles of up to `group` frames per launch, so their pipelines
+    // fill and drain once per group instead of once per frame
+    for (int i = 0; i < nframes; i += group) {
+        const int nf = nframes - i < group ? nframes - i : group;
+        const int rc = launch_frames(e, static_cast<const uint8_t *>(dev_y) + (size_t)i * stride,
+                                     static_cast<uint8_t *>(dev_rec) + (size_t)i * stride, nf, stride);
+        if (rc) return rc;
+    }
+    return QCNN_OK;
+}
+
+int qcnn_batch_group(qcnn_t *e, int set, int *current)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    if (set > 0) e->group = set;
+    if (current) *current = e->group;
+    return QCNN_OK;
 }
 
 int qcnn_forward_blu_layered(qcnn_t *e)

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
-    const int ntiles = tiles_x * ((H + TH - 1) / TH);
+    const int tpf = tiles_x * ((H + TH - 1) / TH);  // tiles per frame
+    const int ntiles = tpf * a.nframes;
     const int first = blockIdx.x, stride = gridDim.x;
     const int N = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;  // tiles of this workgroup
     STAMP_INIT();
@@ -90,15 +91,17 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         constexpr int YLOADS = (9 * YWC + 63) / 64;  // bytes of the private Y tile per lane
         unsigned char ypre[YLOADS];
         auto fetch_y = [&](int t) {
-            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            const int f = t / tpf, tf = t - f * tpf;
+            const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
             const int x0 = tx * TW, y0 = ty * TH;
+            const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
 #pragma unroll
             for (int it = 0; it < YLOADS; ++it) {
                 const int idx = it * 64 + lane;
                 const int row = idx / YWC, col = idx - row * YWC;
                 const int gy = y0 - 4 + PROD_ROWS * p + row, gx = x0 - 4 + col;
                 unsigned char v = 0x80;  // I1.ppro of the zero padding: (x - 128) == 0
-                if (idx < 9 * YWC && gy >= 0 && gy < H && gx >= 0 && gx < W) v = a.y[(size_t)gy * W + gx];
+                if (idx < 9 * YWC && gy >= 0 && gy < H && gx >= 0 && gx < W) v = yf[(size_t)gy * W + gx];
                 ypre[it] = v ^ 0x80;
             }
         };
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
             STAMP();
             if (n < N) {
                 const int t = first + n * stride;
-                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                const int tf = t % tpf;
+                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
                 unsigned char *buf = smem + (n & 1) * SC1_BYTES;
 #pragma unroll
@@ -210,8 +214,10 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
             STAMP();
             if (n >= 1) {
                 const int t = first + (n - 1) * stride;
-                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                const int f = t / tpf, tf = t - f * tpf;
+                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
+                int8_t *concf = a.conc1 + (size_t)f * a.conc_stride;
                 const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
                 v4i acc21[2][8], acc22[8];
 #pragma unroll
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                     const unsigned d2 = quant4<EXACT>(acc22[y][0], acc22[y][1], acc22[y][2], acc22[y][3], bf[8], bf[9],
                                                       bf[10], bf[11], q22);
                     if (gy < H && gx < W) {
-                        unsigned *dst = reinterpret_cast<unsigned *>(a.conc1 + ((size_t)gy * W + gx) * 48 + 12 * g);
+                        unsigned *dst = reinterpret_cast<unsigned *>(concf + ((size_t)gy * W + gx) * 48 + 12 * g);
                         dst[0] = d0;
                         dst[1] = d1;
                         dst[2] = d2;
@@ -273,7 +279,8 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
 
 hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s)
 {
-    const int ntiles = ((a.W + ka::TW - 1) / ka::TW) * ((a.H + ka::TH - 1) / ka::TH);
+    const int ntiles = ((a.W + ka::TW - 1) / ka::TW) * ((a.H + ka::TH - 1) / ka::TH) * a.nframes;
+    if (ntiles < 1) return hipSuccess;
     const int ncu = a.ncu > 0 ? a.ncu : 256;
     dim3 grid(ntiles < ncu ? ntiles : ncu);
     if (exact) hipLaunchKernelGGL(k_c1c2<true>, grid, dim3(512), 0, s, a);

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
-    const int ntiles = tiles_x * ((H + TH - 1) / TH);
+    const int tpf = tiles_x * ((H + TH - 1) / TH);  // tiles per frame
+    const int ntiles = tpf * a.nframes;
     const int first = blockIdx.x, stride = gridDim.x;
     const int N = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;  // tiles of this workgroup
     const int c = lane & 15, g = lane >> 4;
@@ -56,8 +57,10 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
             v4i v[ITER];
             if (n < N) {
                 const int t = first + n * stride;
-                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                const int f = t / tpf, tf = t - f * tpf;
+                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
+                const int8_t *concf = a.conc1 + (size_t)f * a.conc_stride;
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
                     const int pi = it * 256 + mtid;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     const int gy = y0 - 2 + row, gx = x0 - 2 + px;
                     v[it] = v4i{0, 0, 0, 0};
                     if (pi < PIECES && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                        v[it] = *reinterpret_cast<const v4i *>(a.conc1 + ((size_t)gy * W + gx) * 48 + ch * 16);
+                        v[it] = *reinterpret_cast<const v4i *>(concf + ((size_t)gy * W + gx) * 48 + ch * 16);
                 }
             }
             // (2) C4 (3x3, 48 -> 1) + applyRes_y on the conc2 tile n-2.  The three kernel rows r are
@@ -74,8 +77,11 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
             // D_{y+1}[1] + D_{y+2}[2] stays inside one lane.
             if (n >= 2) {
                 const int t = first + (n - 2) * stride;
-                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                const int f = t / tpf, tf = t - f * tpf;
+                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
+                const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
+                uint8_t *recf = a.rec + (size_t)f * a.frame_stride;
                 const unsigned char *sC3 = sC3Base + (n & 1) * SC3_BYTES;
                 const int ox = cb + c;
                 const int gx = x0 + ox;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
 #pragma unroll
                 for (int y = 0; y < 9; ++y) {
                     const int gy = y0 + O0 + y;
-                    ypix[y] = a.y[(size_t)(gy < H ? gy : H - 1) * W + gxc];
+                    ypix[y] = yf[(size_t)(gy < H ? gy : H - 1) * W + gxc];
                 }
                 const unsigned char *rowbase = sC3 + (O0 * C3C + cb + c) * PX + gk * 16;
                 v4i D[11];
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                             int temp = (int)u;                // applyRes_GPU_y, inference/cnn.cu:515-520
                             temp = (int)((unsigned)temp * (unsigned)mul + (1u << (shift - 1))) >> shift;
                             const short rec = (short)((int)ypix[y] + temp);
-                            a.rec[(size_t)gy * W + gx] = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
+                            recf[(size_t)gy * W + gx] = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
                         }
                     }
                 }
@@ -161,7 +167,8 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
             STAMP();
             if (n >= 1 && n <= N) {
                 const int t = first + (n - 1) * stride;
-                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                const int tf = t % tpf;
+                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
                 const unsigned char *sIn = sInBase + ((n - 1) & 1) * SIN_BYTES;
                 unsigned char *sC3 = sC3Base + ((n - 1) & 1) * SC3_BYTES;
@@ -229,7 +236,8 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
 
 hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s)
 {
-    const int ntiles = ((a.W + kb::TW - 1) / kb::TW) * ((a.H + kb::TH - 1) / kb::TH);
+    const int ntiles = ((a.W + kb::TW - 1) / kb::TW) * ((a.H + kb::TH - 1) / kb::TH) * a.nframes;
+    if (ntiles < 1) return hipSuccess;
     const int ncu = a.ncu > 0 ? a.ncu : 256;
     dim3 grid(ntiles < ncu ? ntiles : ncu);
     if (exact) hipLaunchKernelGGL(k_c3c4<true>, grid, dim3(512), 0, s, a);

@@ -68,7 +68,10 @@ struct PackedOffsets {
 struct FusedArgs {
     const uint8_t *y;        // I1.x       uint8 [H][W]
     uint8_t *rec;            // I1.x_rec   uint8 [H][W]
-    int8_t *conc1;           // [H][W][48] int8, internal channel order (see pack_position())
+    int8_t *conc1;           // [nframes][H][W][48] int8, internal channel order (see pos_of_refch())
+    int nframes;             // frames of this launch; frame f lives at y/rec + f*frame_stride
+    size_t frame_stride;     // bytes between consecutive frames of y and of rec
+    size_t conc_stride;      // bytes between consecutive frames of conc1
     const int8_t *wpack;     // packed fragments, PackedOffsets
     const int *bias_i;       // int32 biases, 6 layers concatenated: 64,32,16,16,32,1 (=161)
     const float *bias_f;     // same, converted to float as CovLayer::load_static_para does

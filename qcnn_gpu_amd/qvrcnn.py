@@ -101,6 +101,12 @@ class qvrcnn:
     def bind_io(self, dev_y: int, dev_rec: int) -> None:
         capi.check(self._lib.qcnn_bind_io(self._h, C.c_void_p(dev_y), C.c_void_p(dev_rec)))
 
+    def batch_group(self, set_to: int = 0) -> int:
+        """Frames per kernel launch of forward_blu_batch; set_to > 0 changes it."""
+        cur = C.c_int()
+        capi.check(self._lib.qcnn_batch_group(self._h, int(set_to), C.byref(cur)))
+        return cur.value
+
     def set_timing(self, on: bool) -> None:
         capi.check(self._lib.qcnn_set_timing(self._h, int(on)))
 

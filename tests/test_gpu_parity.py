@@ -162,6 +162,42 @@ def test_full_hd_frame_bit_exact():
         assert np.array_equal(net.tap(capi.TAP_CONC2), taps_o["conc2"])
 
 
+@pytest.mark.parametrize("group", [1, 3, 16])
+def test_batch_of_frames_any_group(group):
+    """The frame loop of inference/kernel.cu:91-97 on resident frames: 7 distinct frames with a
+    padded stride, grouped 1, 3 (ragged last group) and 16 (> batch) frames per kernel launch."""
+    qp, h, w, nf = 27, 53, 95, 7
+    stride = h * w + 37
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    frames = synth.synth_frames(h, w, qp, frames=nf, seed=99)[1]
+    lib = capi.load()
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    capi.check(lib.qcnn_dev_alloc(C.byref(d_in), nf * stride))
+    capi.check(lib.qcnn_dev_alloc(C.byref(d_out), nf * stride))
+    capi.check(lib.qcnn_dev_memset(d_out, 0xAB, nf * stride))
+    for i in range(nf):
+        f = np.ascontiguousarray(frames[i])
+        capi.check(lib.qcnn_dev_h2d(C.c_void_p(d_in.value + i * stride), f.ctypes.data, h * w))
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        assert net.batch_group(group) == group
+        net.forward_blu_batch(d_in.value, d_out.value, nf, stride)
+        net.synchronize()
+        out = np.empty(nf * stride, np.uint8)
+        capi.check(lib.qcnn_dev_d2h(out.ctypes.data, d_out, nf * stride))
+        for i in range(nf):
+            rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(frames[i]))
+            assert np.array_equal(out[i * stride:i * stride + h * w].reshape(h, w), rec_o), f"frame {i}"
+            if i + 1 < nf:
+                assert (out[i * stride + h * w:(i + 1) * stride] == 0xAB).all()   # padding untouched
+        # a single-frame pass afterwards still works on the engine's own buffers
+        net.load_data(np.ascontiguousarray(frames[2]))
+        net.forward_blu()
+        assert np.array_equal(net.download(), c_oracle.forward_blu(mb, np.ascontiguousarray(frames[2])))
+    capi.check(lib.qcnn_dev_free(d_in))
+    capi.check(lib.qcnn_dev_free(d_out))
+
+
 def test_tile_independence_property():
     """Size-independent property: the output at a pixel depends only on its 13x13 neighbourhood, so a
     crop taken 6 pixels inside a larger frame equals the same region of the full result."""
