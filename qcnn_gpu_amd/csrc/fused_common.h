@@ -21,6 +21,8 @@
 // pipeline literally and is bit-exact for every possible model.
 #pragma once
 #include "qcnn_internal.h"
+#include <utility>
+#include <type_traits>
 
 namespace qcnn {
 
@@ -93,6 +95,19 @@ __device__ __forceinline__ unsigned quant4(int a0, int a1, int a2, int a3, float
         const unsigned hi = __builtin_amdgcn_perm(requant_prod(a3, q), requant_prod(a2, q), q.sel2);
         return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
     }
+}
+
+// Calls f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>) in order: a loop
+// whose index is a constant expression in the body.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
 }
 
 // Byte offset of 16-byte channel chunk `chunk` (0..3) inside the 64-byte pixel at LDS column

@@ -13,6 +13,9 @@
 
 namespace qcnn {
 
+constexpr int TILE_ROT = 37;    // rotation of the workgroup -> tile map between rounds
+constexpr int C3_PREFETCH = 6;  // B fragments requested ahead of their MFMAs in the C3 stage
+
 __device__ __forceinline__ void step_barrier_b()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -34,7 +37,14 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
     const int tpf = tiles_x * ((H + TH - 1) / TH);  // tiles per frame
     const int ntiles = tpf * a.nframes;
     const int first = blockIdx.x, stride = gridDim.x;
-    const int N = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;  // tiles of this workgroup
+    const int N = (ntiles + stride - 1) / stride;  // rounds: every workgroup takes at most one tile per round
+    // Tile of this workgroup in round n (-1: none).  The position inside a round rotates by
+    // TILE_ROT per round, so no workgroup is handed a frame-edge column in every round.
+    auto tile_at = [&](int n) -> int {
+        if (n < 0 || n >= N) return -1;
+        const int t = n * stride + (first + n * TILE_ROT) % stride;
+        return t < ntiles ? t : -1;
+    };
     const int c = lane & 15, g = lane >> 4;
     STAMP_INIT();
 
@@ -50,34 +60,55 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
         constexpr int PIECES_ROW = INC * 3;  // 16-byte pieces per tile row
         constexpr int PIECES = INR * PIECES_ROW;
         constexpr int ITER = (PIECES + 255) / 256;
+        static_assert((ITER - 1) * 256 <= PIECES, "only the last piece of a lane may fall outside the tile");
+        // piece `it` of this lane: tile-invariant global offset (relative to the tile's first
+        // halo pixel), LDS offset, and row | column << 8 | chunk << 16 for frame-edge tiles
+        int goff[ITER], soff[ITER], rpc[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int pi = it * 256 + mtid;
+            const int row = pi / PIECES_ROW, rem = pi - row * PIECES_ROW;
+            const int px = rem / 3, ch = rem - px * 3;
+            goff[it] = (row * W + px) * 48 + ch * 16;
+            soff[it] = (row * INC + px) * 64 + swz(ch, px);
+            rpc[it] = row | (px << 8) | (ch << 16);
+        }
+        const bool last_valid = (ITER - 1) * 256 + mtid < PIECES;
         const int cb = (p & 1) * 16, O0 = (p >> 1) * 9;  // C4: wave = 9 output rows x 16 columns
         for (int n = 0; n <= N + 1; ++n) {
             STAMP();
             // (1) request the conc1 tile n: rows y0-2 .. y0+TH+1, cols x0-2 .. x0+TW+1, zero outside
             v4i v[ITER];
-            if (n < N) {
-                const int t = first + n * stride;
-                const int f = t / tpf, tf = t - f * tpf;
+            unsigned outside = 0;  // bit it: piece `it` lies outside the frame (zero padding of C3)
+            const int tl = tile_at(n);
+            if (tl >= 0) {
+                const int f = tl / tpf, tf = tl - f * tpf;
                 const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
-                const int8_t *concf = a.conc1 + (size_t)f * a.conc_stride;
+                const int8_t *frame = a.conc1 + (size_t)f * a.conc_stride;
+                if (y0 >= 2 && y0 - 2 + INR <= H && x0 >= 2 && x0 - 2 + INC <= W) {  // tile + halo inside the frame
+                    const int8_t *org = frame + ((size_t)(y0 - 2) * W + (x0 - 2)) * 48;
 #pragma unroll
-                for (int it = 0; it < ITER; ++it) {
-                    const int pi = it * 256 + mtid;
-                    const int row = pi / PIECES_ROW, rem = pi - row * PIECES_ROW;
-                    const int px = rem / 3, ch = rem - px * 3;
-                    const int gy = y0 - 2 + row, gx = x0 - 2 + px;
-                    v[it] = v4i{0, 0, 0, 0};
-                    if (pi < PIECES && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                        v[it] = *reinterpret_cast<const v4i *>(concf + ((size_t)gy * W + gx) * 48 + ch * 16);
+                    for (int it = 0; it < ITER; ++it) {
+                        v[it] = v4i{0, 0, 0, 0};
+                        if (it + 1 < ITER || last_valid) v[it] = *reinterpret_cast<const v4i *>(org + goff[it]);
+                    }
+                } else {  // frame edge: clamped addresses, branch-free; the pieces outside are zeroed in (3)
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) {
+                        const int gy = y0 - 2 + (rpc[it] & 0xff), gx = x0 - 2 + ((rpc[it] >> 8) & 0xff);
+                        const int cy = gy < 0 ? 0 : gy >= H ? H - 1 : gy, cx = gx < 0 ? 0 : gx >= W ? W - 1 : gx;
+                        if (cy != gy || cx != gx) outside |= 1u << it;
+                        v[it] = *reinterpret_cast<const v4i *>(frame + ((size_t)cy * W + cx) * 48 + (rpc[it] >> 16) * 16);
+                    }
                 }
             }
             // (2) C4 (3x3, 48 -> 1) + applyRes_y on the conc2 tile n-2.  The three kernel rows r are
             // MFMA rows 0..2: D_yy[r][pixel] = sum_s W4[r][s] . X[yy][pixel+s], and out[y] = D_y[0] +
             // D_{y+1}[1] + D_{y+2}[2] stays inside one lane.
-            if (n >= 2) {
-                const int t = first + (n - 2) * stride;
-                const int f = t / tpf, tf = t - f * tpf;
+            const int tc = tile_at(n - 2);
+            if (tc >= 0) {
+                const int f = tc / tpf, tf = tc - f * tpf;
                 const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
                 const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
@@ -120,15 +151,16 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 }
             }
             // (3) the requested tile lands in LDS buffer n&1
-            if (n < N) {
+            if (tl >= 0) {
                 unsigned char *sIn = sInBase + (n & 1) * SIN_BYTES;
+                if (outside != 0) {
 #pragma unroll
-                for (int it = 0; it < ITER; ++it) {
-                    const int pi = it * 256 + mtid;
-                    const int row = pi / PIECES_ROW, rem = pi - row * PIECES_ROW;
-                    const int px = rem / 3, ch = rem - px * 3;
-                    if (pi < PIECES) *reinterpret_cast<v4i *>(sIn + (row * INC + px) * 64 + swz(ch, px)) = v[it];
+                    for (int it = 0; it < ITER; ++it)
+                        if (outside >> it & 1) v[it] = v4i{0, 0, 0, 0};
                 }
+#pragma unroll
+                for (int it = 0; it < ITER; ++it)
+                    if (it + 1 < ITER || last_valid) *reinterpret_cast<v4i *>(sIn + soff[it]) = v[it];
             }
             STAMP();
             step_barrier_b();
@@ -163,51 +195,56 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
 #pragma unroll
             for (int i = 0; i < 12; ++i) bf[i] = 0.f;
         }
+        v4i b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};  // integer path: bias starts the accumulator
+        if constexpr (!EXACT) {
+            b0 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[3] + 4 * g);
+            b1 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[4] + 4 * g);
+            b2 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[4] + 16 + 4 * g);
+        }
         for (int n = 0; n <= N + 1; ++n) {
             STAMP();
-            if (n >= 1 && n <= N) {
-                const int t = first + (n - 1) * stride;
+            const int t = tile_at(n - 1);
+            if (t >= 0) {
                 const int tf = t % tpf;
                 const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
                 const unsigned char *sIn = sInBase + ((n - 1) & 1) * SIN_BYTES;
                 unsigned char *sC3 = sC3Base + ((n - 1) & 1) * SC3_BYTES;
                 v4i acc31[10], acc32[2][10];
-                {
-                    v4i b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
-                    if constexpr (!EXACT) {
-                        b0 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[3] + 4 * g);
-                        b1 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[4] + 4 * g);
-                        b2 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[4] + 16 + 4 * g);
-                    }
 #pragma unroll
-                    for (int y = 0; y < 10; ++y) {
-                        acc31[y] = b0;
-                        acc32[0][y] = b1;
-                        acc32[1][y] = b2;
-                    }
+                for (int y = 0; y < 10; ++y) {
+                    acc31[y] = b0;
+                    acc32[0][y] = b1;
+                    acc32[1][y] = b2;
                 }
-                // region (i, jj) <-> image (y0-1+i, x0-1+jj); tap (r, s) reads tile (i+r, jj+s)
+                // region (i, jj) <-> image (y0-1+i, x0-1+jj); tap (r, s) reads tile (i+r, jj+s).
+                // Step I = 12 s + yy issues every MFMA that uses the B fragment of (input row yy,
+                // column shift s) and requests the fragment of step I + C3_PREFETCH; the scheduling
+                // fence after each step keeps that many LDS reads in flight ahead of their use.
                 const unsigned char *rowbase = sIn + (R0 * INC + cb + c) * 64;
+                const unsigned char *colbase[3];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const unsigned char *colbase = rowbase + s * 64 + swz(g, cb + c + s);
+                for (int s = 0; s < 3; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
+                v4i Bq[36];
 #pragma unroll
-                    for (int yy = 0; yy < 12; ++yy) {
-                        const v4i B = *reinterpret_cast<const v4i *>(colbase + yy * (INC * 64));
+                for (int I = 0; I < C3_PREFETCH; ++I)
+                    Bq[I] = *reinterpret_cast<const v4i *>(colbase[I / 12] + (I % 12) * (INC * 64));
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<36>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    constexpr int s = I / 12, yy = I % 12;
+                    constexpr int J = I + C3_PREFETCH;
+                    if constexpr (J < 36) Bq[J] = *reinterpret_cast<const v4i *>(colbase[J / 12] + (J % 12) * (INC * 64));
+                    const v4i B = Bq[I];
+                    constexpr int lo = yy - 2 > 0 ? yy - 2 : 0, hi = yy < 9 ? yy : 9;  // output rows fed
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            const int y = yy - r;
-                            if (y >= 0 && y < 10) {
-                                acc31[y] = mfma16(f31[s][r], B, acc31[y]);
-                                if (s == 1 && r == 1) {
-                                    acc32[0][y] = mfma16(f32[0], B, acc32[0][y]);
-                                    acc32[1][y] = mfma16(f32[1], B, acc32[1][y]);
-                                }
-                            }
-                        }
+                    for (int y = lo; y <= hi; ++y) acc31[y] = mfma16(f31[s][yy - y], B, acc31[y]);
+                    if constexpr (s == 1 && yy >= 1 && yy <= 10) {
+                        acc32[0][yy - 1] = mfma16(f32[0], B, acc32[0][yy - 1]);
+                        acc32[1][yy - 1] = mfma16(f32[1], B, acc32[1][yy - 1]);
                     }
-                }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
                 STAMP();
                 mfma_drain();
                 const int jj = cb + c;

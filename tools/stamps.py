@@ -20,10 +20,12 @@ net.load_static_para(synth.synth_model(qp).to_nchw_vect_c_bytes())
 net.load_data(synth.synth_frames(h, w, qp)[1][0])
 lib = capi.load()
 buf = np.zeros((16, 128), np.uint64)
-for it in range(3):
+net.set_timing(True)
+for it in range(20):
     net.forward_blu()
     net.synchronize()
     lib.qcnn_debug_stamps(net._h, buf.ctypes.data_as(C.c_void_p))
+print("kernel times (us) k_c1c2, k_c3c4, passes:", net.kernel_times_us())
 # both kernels stamp into the same buffer: kernel B's stamps overwrite the first slots of waves 0-3
 t0 = buf[buf > 0].min()
 for wv in range(16):
