@@ -110,6 +110,18 @@ __device__ __forceinline__ void static_for(F &&f)
     static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
 }
 
+// The same over LO .. HI-1.
+template <int LO, typename F, int... I>
+__device__ __forceinline__ void static_range_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, LO + I>{}), ...);
+}
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void static_range(F &&f)
+{
+    if constexpr (HI > LO) static_range_impl<LO>(static_cast<F &&>(f), std::make_integer_sequence<int, HI - LO>{});
+}
+
 // Byte offset of 16-byte channel chunk `chunk` (0..3) inside the 64-byte pixel at LDS column
 // `col`: the chunk position is rotated by col/2.  With it the 16-lane groups of a ds_read_b128
 // B-fragment read (16 consecutive pixels x 4 chunks) hit 16 distinct 16-byte bank slots, and the
@@ -132,7 +144,10 @@ __device__ __forceinline__ void stamp(unsigned long long *dbg, int blk, int wv, 
     ++idx;
     __builtin_amdgcn_sched_barrier(0);
 }
-#define STAMP() stamp(a.dbg, a.dbg_block, wv, stamp_idx)
+#ifndef STAMP_ROW
+#define STAMP_ROW wv
+#endif
+#define STAMP() stamp(a.dbg, a.dbg_block, STAMP_ROW, stamp_idx)
 #define STAMP_INIT() int stamp_idx = 0
 #else
 #define STAMP() do { } while (0)

@@ -11,23 +11,46 @@
 
 namespace qcnn {
 
-// A fragments of one kernel column s of the C2 stage: C2_2 rows r = 0..4 and, for the three inner
-// columns, C2_1 rows r' = 0..2 x two 16-channel tiles.
-struct C2Weights {
-    v4i f22[5];
-    v4i f21[3][2];
+// Load plan of the C2 stage of one consumer tile.  Step I = 12 s + yy issues every MFMA that uses
+// the B fragment of (input row yy, kernel column s).  The LDS reads of a tile (60 B fragments, 25
+// C2_2 and 18 C2_1 A fragments) are numbered in the order the steps first need them; need[I] is the
+// number of reads that must have been issued before step I.  The kernel issues the reads of step
+// I + C2_PREFETCH while it runs the MFMAs of step I.
+struct C2Plan {
+    int kind[103];  // 0: B fragment (s, yy); 1: C2_2 A fragment (s, r); 2: C2_1 A fragment (s-1, r-1, t)
+    int a0[103], a1[103], a2[103];
+    int need[60];
+    int iB[5][12], i22[5][5], i21[3][3][2];
+    int n;
 };
-__device__ __forceinline__ void load_c2_weights(const v4i *w22, const v4i *w21, int s, C2Weights &o)
+constexpr C2Plan make_c2_plan()
 {
-#pragma unroll
-    for (int r = 0; r < 5; ++r) o.f22[r] = w22[(s * 5 + r) * 64];
-    if (s >= 1 && s <= 3) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            o.f21[r][0] = w21[(((s - 1) * 3 + r) * 2 + 0) * 64];
-            o.f21[r][1] = w21[(((s - 1) * 3 + r) * 2 + 1) * 64];
+    C2Plan p{};
+    int n = 0;
+    for (int s = 0; s < 5; ++s)
+        for (int yy = 0; yy < 12; ++yy) {
+            p.iB[s][yy] = n;
+            p.kind[n] = 0, p.a0[n] = s, p.a1[n] = yy, ++n;
+            if (yy < 5) {  // kernel row r = yy is first used here (output row 0)
+                p.i22[s][yy] = n;
+                p.kind[n] = 1, p.a0[n] = s, p.a1[n] = yy, ++n;
+                if (s >= 1 && s <= 3 && yy >= 1 && yy <= 3)
+                    for (int t = 0; t < 2; ++t) {
+                        p.i21[s - 1][yy - 1][t] = n;
+                        p.kind[n] = 2, p.a0[n] = s - 1, p.a1[n] = yy - 1, p.a2[n] = t, ++n;
+                    }
+            }
+            p.need[s * 12 + yy] = n;
         }
-    }
+    p.n = n;
+    return p;
+}
+constexpr C2Plan C2P = make_c2_plan();
+static_assert(C2P.n == 103, "60 B fragments + 25 + 18 A fragments");
+constexpr int C2_PREFETCH = 4;  // steps of look-ahead of the LDS reads
+constexpr int c2_issued(int I)  // reads issued once step I has issued its own
+{
+    return I < 0 ? C2P.need[C2_PREFETCH - 1] : C2P.need[I + C2_PREFETCH < 60 ? I + C2_PREFETCH : 59];
 }
 
 // End of a pipeline step: every LDS write of this wave has landed, then the workgroup barrier.
@@ -70,10 +93,16 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         // Producer p owns C1 region rows 5p .. 5p+4 (all C1C columns): 180 pixels = 6 MFMA pixel
         // tiles of 32.  It needs Y tile rows 5p .. 5p+8, which it loads itself into a private LDS
         // image, so producers never wait for each other.
+        //
+        // The private image holds FOUR copies of the Y tile, copy c shifted left by c bytes, so the
+        // 8 bytes Y[row][j .. j+7] of any column j are two aligned dwords of copy j&3: the im2col
+        // B fragment of a pixel is read straight from LDS.  C1 is then two chained 32x32x32 MFMAs
+        // per 32-channel tile: K = (kernel row pair, 8 columns), weights zero for columns 5..7 and
+        // rows >= 5, so whatever the padding bytes hold is multiplied by zero.
         const int p = wv;
-        unsigned char *sYw = sYall + p * SYW_BYTES;  // [YWR][YWC] int8 (x - 128), 0 outside the frame
-        const v4i *wp = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C1W);
-        const v4i A0 = wp[lane], A1 = wp[64 + lane];
+        unsigned char *sYw = sYall + p * SYW_BYTES;  // [4][YWR][YWS] int8 (x - 128), 0 outside the frame
+        const v4i *wp = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C1W) + lane;
+        const v4i A00 = wp[0], A01 = wp[64], A10 = wp[128], A11 = wp[192];  // [channel tile][row group]
         const int h = lane >> 5;
         const Requant q = a.rq[0];
         v16i bias0 = {}, bias1 = {};
@@ -88,21 +117,57 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 bf1[i] = a.bias_f[32 + 16 * h + i];
             }
         }
+        // per-lane constants of the six pixel groups k: LDS read address (k-group h = kernel rows
+        // 2h, 2h+1; rows 4, 5 sit 4 rows further), LDS write address, region coordinates
+        constexpr int NPIX = PROD_ROWS * C1C;  // 180
+        constexpr int NK = (NPIX + 31) / 32;
+        int rd[NK], wr[NK], ij[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int qi = k * 32 + (lane & 31);
+            const int qc = qi < NPIX ? qi : NPIX - 1;
+            const int il = qc / C1C, j = qc - il * C1C;
+            const int cc = j & 3;
+            rd[k] = cc * YCOPY + (il + 2 * h) * YWS + (j - cc) + 4;
+            const int i = PROD_ROWS * p + il;
+            wr[k] = (i * C1C + j) * 64 + swz(h, j);
+            ij[k] = i | (j << 8);
+        }
+        const bool last_valid = (NK - 1) * 32 + (lane & 31) < NPIX;
         constexpr int YLOADS = (9 * YWC + 63) / 64;  // bytes of the private Y tile per lane
+        // byte `it` of this lane: offset in the frame relative to the tile's first halo pixel, LDS
+        // offset in copy 0 (copy c sits c * (YCOPY - 1) further; -1: no byte), row | column << 8
+        int yoff[YLOADS], ywr[YLOADS], yrc[YLOADS];
+#pragma unroll
+        for (int it = 0; it < YLOADS; ++it) {
+            const int idx = it * 64 + lane;
+            const int row = idx / YWC, col = idx - row * YWC;
+            yoff[it] = row * W + col;
+            ywr[it] = idx < 9 * YWC ? row * YWS + col + 4 : -1;
+            yrc[it] = row | (col << 8);
+        }
         unsigned char ypre[YLOADS];
         auto fetch_y = [&](int t) {
             const int f = t / tpf, tf = t - f * tpf;
             const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-            const int x0 = tx * TW, y0 = ty * TH;
+            const int xa = tx * TW - 4, ya = ty * TH - 4 + PROD_ROWS * p;  // first halo pixel of this producer
             const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
+            if (xa >= 0 && xa + YWC <= W && ya >= 0 && ya + 9 <= H) {  // inside the frame
+                const uint8_t *org = yf + (size_t)ya * W + xa;
 #pragma unroll
-            for (int it = 0; it < YLOADS; ++it) {
-                const int idx = it * 64 + lane;
-                const int row = idx / YWC, col = idx - row * YWC;
-                const int gy = y0 - 4 + PROD_ROWS * p + row, gx = x0 - 4 + col;
-                unsigned char v = 0x80;  // I1.ppro of the zero padding: (x - 128) == 0
-                if (idx < 9 * YWC && gy >= 0 && gy < H && gx >= 0 && gx < W) v = yf[(size_t)gy * W + gx];
-                ypre[it] = v ^ 0x80;
+                for (int it = 0; it < YLOADS; ++it) {
+                    unsigned char v = 0;
+                    if (it + 1 < YLOADS || ywr[it] >= 0) v = org[yoff[it]];
+                    ypre[it] = v ^ 0x80;
+                }
+            } else {  // frame edge: clamped addresses; I1.ppro of the zero padding is (x - 128) == 0
+#pragma unroll
+                for (int it = 0; it < YLOADS; ++it) {
+                    const int gy = ya + (yrc[it] & 0xff), gx = xa + (yrc[it] >> 8);
+                    const int cy = gy < 0 ? 0 : gy >= H ? H - 1 : gy, cx = gx < 0 ? 0 : gx >= W ? W - 1 : gx;
+                    const unsigned char v = yf[(size_t)cy * W + cx];
+                    ypre[it] = (cy == gy && cx == gx) ? (v ^ 0x80) : 0;
+                }
             }
         };
         if (N > 0) fetch_y(first);
@@ -116,39 +181,33 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 unsigned char *buf = smem + (n & 1) * SC1_BYTES;
 #pragma unroll
                 for (int it = 0; it < YLOADS; ++it) {
-                    const int idx = it * 64 + lane;
-                    if (idx < 9 * YWC) sYw[idx] = ypre[it];
+                    if (ywr[it] >= 0) {
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) sYw[ywr[it] + cc * (YCOPY - 1)] = ypre[it];
+                    }
                 }
                 if (n + 1 < N) fetch_y(t + stride);  // next tile's bytes travel while this one is computed
-                const unsigned *sYd = reinterpret_cast<const unsigned *>(sYw);
-                constexpr int NPIX = PROD_ROWS * C1C;  // 180
-#pragma unroll 1
-                for (int k = 0; k < (NPIX + 31) / 32; ++k) {
-                    const int qi = k * 32 + (lane & 31);
-                    const int qc = qi < NPIX ? qi : NPIX - 1;
-                    const int il = qc / C1C, j = qc - il * C1C;
-                    // B fragment = 16 bytes of im2col: k-group h covers kernel rows 3h..3h+2; bytes
-                    // 0..11 = the three rows at columns j..j+3, bytes 12..14 = column j+4, byte 15 = 0
-                    const int sh = j & 3;
-                    unsigned lo4[3], b5[3];
-#pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) {
-                        const int d = (il + 3 * h + rr) * (YWC / 4) + (j >> 2);
-                        const unsigned lo = sYd[d], hi = sYd[d + 1];
-                        lo4[rr] = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                        b5[rr] = (hi >> (8 * sh)) & 0xffu;
-                    }
-                    v4i B;
-                    B.x = (int)lo4[0];
-                    B.y = (int)lo4[1];
-                    B.z = (int)lo4[2];
-                    B.w = (int)(b5[0] | (b5[1] << 8) | (b5[2] << 16));
-                    v16i d0 = mfma32(A0, B, bias0);
-                    v16i d1 = mfma32(A1, B, bias1);
-                    mfma_drain();
-                    const int i = PROD_ROWS * p + il;
-                    const int gy = y0 - 2 + i, gx = x0 - 2 + j;
-                    const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                // frame-edge tiles zero the C1 outputs that lie outside the frame (zero padding of C2)
+                const bool edge = y0 < 2 || y0 - 2 + C1R > H || x0 < 2 || x0 - 2 + C1C > W;
+                // C1 MFMAs of pixel group k: the B fragments come straight from the shifted copies
+                auto c1_mfma = [&](int k, v16i &d0, v16i &d1) {
+                    const unsigned *src = reinterpret_cast<const unsigned *>(sYw + rd[k]);
+                    v4i B1, B2;
+                    B1.x = (int)src[0];
+                    B1.y = (int)src[1];
+                    B1.z = (int)src[YWS / 4];
+                    B1.w = (int)src[YWS / 4 + 1];
+                    B2.x = (int)src[YWS];       // 4 rows further: kernel row 4 for k-group 0
+                    B2.y = (int)src[YWS + 1];
+                    B2.z = B2.x;                // kernel row 5: zero weights
+                    B2.w = B2.y;
+                    d0 = mfma32(A00, B1, bias0);
+                    d1 = mfma32(A10, B1, bias1);
+                    d0 = mfma32(A01, B2, d0);
+                    d1 = mfma32(A11, B2, d1);
+                };
+                // requant + store of pixel group k
+                auto c1_store = [&](int k, const v16i &d0, const v16i &d1) {
                     v4i o0, o1;
                     if constexpr (!EXACT) {
                         o0.x = quant4<false>(d0[0], d0[1], d0[2], d0[3], 0.f, 0.f, 0.f, 0.f, q);
@@ -169,16 +228,31 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                         o1.z = quant4<true>(d1[8], d1[9], d1[10], d1[11], bf1[8], bf1[9], bf1[10], bf1[11], q);
                         o1.w = quant4<true>(d1[12], d1[13], d1[14], d1[15], bf1[12], bf1[13], bf1[14], bf1[15], q);
                     }
-                    if (!inside) {  // zero padding of the C2 input: C1 output does not exist outside the frame
-                        o0 = v4i{0, 0, 0, 0};
-                        o1 = v4i{0, 0, 0, 0};
+                    if (edge) {
+                        const int gy = y0 - 2 + (ij[k] & 0xff), gx = x0 - 2 + (ij[k] >> 8);
+                        if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) {
+                            o0 = v4i{0, 0, 0, 0};
+                            o1 = v4i{0, 0, 0, 0};
+                        }
                     }
-                    if (qi < NPIX) {
-                        unsigned char *px = buf + (i * C1C + j) * 64;
-                        *reinterpret_cast<v4i *>(px + swz(h, j)) = o0;      // channels 16h .. 16h+15
-                        *reinterpret_cast<v4i *>(px + swz(2 + h, j)) = o1;  // channels 32+16h .. 32+16h+15
+                    if (k + 1 < NK || last_valid) {
+                        *reinterpret_cast<v4i *>(buf + wr[k]) = o0;         // channels 16h .. 16h+15
+                        *reinterpret_cast<v4i *>(buf + (wr[k] ^ 32)) = o1;  // channels 32+16h .. 32+16h+15
                     }
-                }
+                };
+                // software pipeline: the MFMAs of group k+1 are in flight while group k is requantised
+                v16i dA0, dA1, dB0, dB1;
+                c1_mfma(0, dA0, dA1);
+                static_for<NK>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k + 1 < NK) {
+                        if constexpr (k & 1) c1_mfma(k + 1, dA0, dA1);
+                        else c1_mfma(k + 1, dB0, dB1);
+                    }
+                    mfma_drain();
+                    if constexpr (k & 1) c1_store(k, dB0, dB1);
+                    else c1_store(k, dA0, dA1);
+                });
             }
             STAMP();
             step_barrier();
@@ -227,28 +301,39 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                     acc22[y] = b2;
                 }
                 const unsigned char *rowbase = buf + (R0 * C1C + cb + c) * 64;
+                const unsigned char *colbase[5];
 #pragma unroll
-                for (int s = 0; s < 5; ++s) {
-                    const bool inner_s = s >= 1 && s <= 3;
-                    C2Weights cur;
-                    load_c2_weights(w22, w21, s, cur);  // A fragments of kernel column s, from LDS
-                    const unsigned char *colbase = rowbase + s * 64 + swz(g, cb + c + s);
-#pragma unroll
-                    for (int yy = 0; yy < 12; ++yy) {
-                        const v4i B = *reinterpret_cast<const v4i *>(colbase + yy * (C1C * 64));
-#pragma unroll
-                        for (int r = 0; r < 5; ++r) {
-                            const int y = yy - r;
-                            if (y >= 0 && y < 8) {
-                                acc22[y] = mfma16(cur.f22[r], B, acc22[y]);
-                                if (inner_s && r >= 1 && r <= 3) {
-                                    acc21[0][y] = mfma16(cur.f21[r - 1][0], B, acc21[0][y]);
-                                    acc21[1][y] = mfma16(cur.f21[r - 1][1], B, acc21[1][y]);
-                                }
+                for (int s = 0; s < 5; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
+                v4i item[C2P.n];
+                auto issue = [&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    if constexpr (C2P.kind[J] == 0)
+                        item[J] = *reinterpret_cast<const v4i *>(colbase[C2P.a0[J]] + C2P.a1[J] * (C1C * 64));
+                    else if constexpr (C2P.kind[J] == 1)
+                        item[J] = w22[(C2P.a0[J] * 5 + C2P.a1[J]) * 64];
+                    else
+                        item[J] = w21[((C2P.a0[J] * 3 + C2P.a1[J]) * 2 + C2P.a2[J]) * 64];
+                };
+                static_range<0, c2_issued(-1)>(issue);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<60>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    constexpr int s = I / 12, yy = I % 12;
+                    static_range<c2_issued(I - 1), c2_issued(I)>(issue);
+                    const v4i B = item[C2P.iB[s][yy]];
+                    static_for<5>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        constexpr int y = yy - r;
+                        if constexpr (y >= 0 && y < 8) {
+                            acc22[y] = mfma16(item[C2P.i22[s][r]], B, acc22[y]);
+                            if constexpr (s >= 1 && s <= 3 && r >= 1 && r <= 3) {
+                                acc21[0][y] = mfma16(item[C2P.i21[s - 1][r - 1][0]], B, acc21[0][y]);
+                                acc21[1][y] = mfma16(item[C2P.i21[s - 1][r - 1][1]], B, acc21[1][y]);
                             }
                         }
-                    }
-                }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
                 // epilogue: lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel tile = 12
                 // consecutive bytes at position 12g of the pixel in the internal channel order.
                 STAMP();

@@ -9,6 +9,7 @@
 //                         and write the conc2 tile n-1 into LDS buffer (n-1)&1.
 // The conc1 tile uses 64-byte pixels with the rotated chunk positions of swz() (48 bytes used), so
 // the C3 B-fragment reads are bank-conflict-free; the conc2 tile keeps dense 48-byte pixels.
+#define STAMP_ROW (wv + 8)  // diagnostic builds: rows 8..15 of the stamp buffer (kernel A owns 0..7)
 #include "fused_common.h"
 
 namespace qcnn {

@@ -33,11 +33,14 @@ constexpr int TH = 16, TW = 32;
 constexpr int C1R = TH + 4, C1C = TW + 4;  // C1 output region held in LDS (halo 2)
 constexpr int PROD_ROWS = C1R / 4;         // C1 region rows per producer wave
 constexpr int YWR = PROD_ROWS + 5, YWC = TW + 8;  // private Y tile of one producer (halo 4 + 1 slack row)
+constexpr int YWS = YWC + 8;               // row stride of one LDS copy of it: 4 bytes lead-in, 4 tail
+constexpr int YCOPY = YWR * YWS;           // bytes of one copy; a producer keeps 4, shifted by 0..3 bytes
 constexpr int SC1_BYTES = C1R * C1C * 64;
-constexpr int SYW_BYTES = YWR * YWC;
+constexpr int SYW_BYTES = 4 * YCOPY;
 constexpr int SW_BYTES = 43 * 1024;        // the 25 + 18 C2 A fragments
 constexpr int LDS_BYTES = 2 * SC1_BYTES + 4 * SYW_BYTES + SW_BYTES;
-static_assert(SYW_BYTES % 16 == 0 && YWC % 4 == 0, "private Y tiles are read as aligned dwords");
+static_assert(SYW_BYTES % 16 == 0 && YWS % 4 == 0, "private Y tiles are read as aligned dwords");
+static_assert(LDS_BYTES <= 160 * 1024, "kernel A exceeds the 160 KiB of LDS of one CU");
 }  // namespace ka
 
 // Kernel B: conc1 -> (C3_1 || C3_2) -> C4 -> residual add, one 18 x 30 output tile per workgroup.
@@ -55,8 +58,8 @@ static_assert(LDS_BYTES <= 160 * 1024, "kernel B exceeds the 160 KiB of LDS of o
 // Offsets (bytes) of the packed MFMA A-operand fragments inside one device buffer.
 // One fragment = 64 lanes x 16 bytes = 1 KiB, stored in lane order.
 struct PackedOffsets {
-    static constexpr int C1W = 0;                       // 2 fragments (32x32x32)
-    static constexpr int C2W22 = C1W + 2 * 1024;        // 25 fragments [s][r]
+    static constexpr int C1W = 0;                       // 4 fragments (32x32x32) [channel tile][row group]
+    static constexpr int C2W22 = C1W + 4 * 1024;        // 25 fragments [s][r]
     static constexpr int C2W21 = C2W22 + 25 * 1024;     // 18 fragments [s'][r'][t]
     static constexpr int C3W31 = C2W21 + 18 * 1024;     // 9 fragments [s][r]
     static constexpr int C3W32 = C3W31 + 9 * 1024;      // 2 fragments [t]

@@ -26,7 +26,7 @@ for it in range(20):
     net.synchronize()
     lib.qcnn_debug_stamps(net._h, buf.ctypes.data_as(C.c_void_p))
 print("kernel times (us) k_c1c2, k_c3c4, passes:", net.kernel_times_us())
-# both kernels stamp into the same buffer: kernel B's stamps overwrite the first slots of waves 0-3
+# rows 0..7: waves of kernel A (k_c1c2); rows 8..15: waves of kernel B (k_c3c4)
 t0 = buf[buf > 0].min()
 for wv in range(16):
     row = buf[wv]
