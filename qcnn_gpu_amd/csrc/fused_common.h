@@ -43,22 +43,12 @@ __device__ __forceinline__ v16i mfma32(v4i a, v4i b, v16i c)
 // (requant(blu) == 127 is part of the proof), and mul/cmul are pre-shifted on the host so that
 // the quotient ((v + bias) * mul) >> shift is a whole byte (byte 2 or 3) of the 32-bit product:
 // the shift is then done by the byte-permute that packs four channels into a dword.
-// The clamp is inline asm (no integer med3 builtin exists and the compiler only forms one from
-// constant bounds).  hipcc does not pad the MFMA-result -> VALU-read hazard for instructions
-// inside an asm statement, so every epilogue that applies med3i to accumulators first calls
-// mfma_drain(): 20 wait states, more than the 11 an 8-pass MFMA needs, fenced so that nothing is
-// scheduled across it.
-__device__ __forceinline__ void mfma_drain()
-{
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
+// The clamp is written as the median identity max(min(x, 0), min(max(x, 0), hi)), which the
+// compiler selects as one v_med3_i32 (a plain min(max(x, 0), hi) with a non-constant bound becomes
+// two instructions).
 __device__ __forceinline__ int med3i(int x, int hi)
 {
-    int r;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
-    return r;
+    return max(min(x, 0), min(max(x, 0), hi));
 }
 __device__ __forceinline__ unsigned requant_prod(int s, const Requant &q)
 {
@@ -81,20 +71,25 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
-// Requantises four consecutive channels (accumulators a0..a3, float biases only used by the
-// EXACT variant) and packs them into one dword.
+// Requantises two consecutive channels (accumulators a0, a1; float biases only used by the EXACT
+// variant) into the low half of a dword; join2 makes a dword of four channels from two halves.
+template <bool EXACT>
+__device__ __forceinline__ unsigned quant2(int a0, int a1, float b0, float b1, const Requant &q)
+{
+    if constexpr (EXACT)
+        return __builtin_amdgcn_perm((unsigned)requant_float(a1, b1, q), (unsigned)requant_float(a0, b0, q), 0x0c0c0400u);
+    else
+        return __builtin_amdgcn_perm(requant_prod(a1, q), requant_prod(a0, q), q.sel2);
+}
+__device__ __forceinline__ unsigned join2(unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
+
+// Requantises four consecutive channels and packs them into one dword (the store-to-char
+// truncation of the reference).
 template <bool EXACT>
 __device__ __forceinline__ unsigned quant4(int a0, int a1, int a2, int a3, float b0, float b1, float b2, float b3,
                                            const Requant &q)
 {
-    if constexpr (EXACT) {
-        return pack4(requant_float(a0, b0, q), requant_float(a1, b1, q), requant_float(a2, b2, q),
-                     requant_float(a3, b3, q));
-    } else {
-        const unsigned lo = __builtin_amdgcn_perm(requant_prod(a1, q), requant_prod(a0, q), q.sel2);
-        const unsigned hi = __builtin_amdgcn_perm(requant_prod(a3, q), requant_prod(a2, q), q.sel2);
-        return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-    }
+    return join2(quant2<EXACT>(a2, a3, b2, b3, q), quant2<EXACT>(a0, a1, b0, b1, q));
 }
 
 // Calls f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>) in order: a loop

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                         if constexpr (k & 1) c1_mfma(k + 1, dA0, dA1);
                         else c1_mfma(k + 1, dB0, dB1);
                     }
-                    mfma_drain();
+                    __builtin_amdgcn_sched_barrier(0);
                     if constexpr (k & 1) c1_store(k, dB0, dB1);
                     else c1_store(k, dA0, dA1);
                 });
@@ -337,7 +337,6 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 // epilogue: lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel tile = 12
                 // consecutive bytes at position 12g of the pixel in the internal channel order.
                 STAMP();
-                mfma_drain();
                 const int gx = x0 + cb + c;
 #pragma unroll
                 for (int y = 0; y < 8; ++y) {

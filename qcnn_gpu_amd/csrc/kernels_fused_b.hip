@@ -247,7 +247,6 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 STAMP();
-                mfma_drain();
                 const int jj = cb + c;
                 const int gx = x0 - 1 + jj;
 #pragma unroll
