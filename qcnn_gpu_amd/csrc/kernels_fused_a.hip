@@ -337,21 +337,37 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 // epilogue: lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel tile = 12
                 // consecutive bytes at position 12g of the pixel in the internal channel order.
                 STAMP();
-                const int gx = x0 + cb + c;
+                const int gx = x0 + cb + c, gy0 = y0 + R0;
+                int8_t *out = concf + ((size_t)gy0 * W + gx) * 48 + 12 * g;  // row y sits y * W * 48 further
+                const size_t row_bytes = (size_t)W * 48;
+                auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
+                    d0 = quant4<EXACT>(acc21[0][y][0], acc21[0][y][1], acc21[0][y][2], acc21[0][y][3], bf[0], bf[1], bf[2],
+                                       bf[3], q21);
+                    d1 = quant4<EXACT>(acc21[1][y][0], acc21[1][y][1], acc21[1][y][2], acc21[1][y][3], bf[4], bf[5], bf[6],
+                                       bf[7], q21);
+                    d2 = quant4<EXACT>(acc22[y][0], acc22[y][1], acc22[y][2], acc22[y][3], bf[8], bf[9], bf[10], bf[11], q22);
+                };
+                if (gy0 + 8 <= H && x0 + cb + 16 <= W) {  // the wave's 8 x 16 pixels are all inside the frame
 #pragma unroll
-                for (int y = 0; y < 8; ++y) {
-                    const int gy = y0 + R0 + y;
-                    const unsigned d0 = quant4<EXACT>(acc21[0][y][0], acc21[0][y][1], acc21[0][y][2], acc21[0][y][3],
-                                                      bf[0], bf[1], bf[2], bf[3], q21);
-                    const unsigned d1 = quant4<EXACT>(acc21[1][y][0], acc21[1][y][1], acc21[1][y][2], acc21[1][y][3],
-                                                      bf[4], bf[5], bf[6], bf[7], q21);
-                    const unsigned d2 = quant4<EXACT>(acc22[y][0], acc22[y][1], acc22[y][2], acc22[y][3], bf[8], bf[9],
-                                                      bf[10], bf[11], q22);
-                    if (gy < H && gx < W) {
-                        unsigned *dst = reinterpret_cast<unsigned *>(concf + ((size_t)gy * W + gx) * 48 + 12 * g);
+                    for (int y = 0; y < 8; ++y) {
+                        unsigned d0, d1, d2;
+                        quant_row(y, d0, d1, d2);
+                        unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
                         dst[0] = d0;
                         dst[1] = d1;
                         dst[2] = d2;
+                    }
+                } else {
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) {
+                        unsigned d0, d1, d2;
+                        quant_row(y, d0, d1, d2);
+                        if (gy0 + y < H && gx < W) {
+                            unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+                            dst[0] = d0;
+                            dst[1] = d1;
+                            dst[2] = d2;
+                        }
                     }
                 }
             }

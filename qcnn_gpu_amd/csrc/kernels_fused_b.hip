@@ -104,6 +104,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     }
                 }
             }
+            STAMP();
             // (2) C4 (3x3, 48 -> 1) + applyRes_y on the conc2 tile n-2.  The three kernel rows r are
             // MFMA rows 0..2: D_yy[r][pixel] = sum_s W4[r][s] . X[yy][pixel+s], and out[y] = D_y[0] +
             // D_{y+1}[1] + D_{y+2}[2] stays inside one lane.
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                         D[yy] = mfma16(f4[s], B, D[yy]);
                     }
                 }
+                STAMP();
                 if (g == 0 && ox < TW && gx < W) {
 #pragma unroll
                     for (int y = 0; y < 9; ++y) {
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     }
                 }
             }
+            STAMP();
             // (3) the requested tile lands in LDS buffer n&1
             if (tl >= 0) {
                 unsigned char *sIn = sInBase + (n & 1) * SIN_BYTES;
@@ -248,21 +251,38 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 });
                 STAMP();
                 const int jj = cb + c;
-                const int gx = x0 - 1 + jj;
+                const int gx = x0 - 1 + jj, gy0 = y0 - 1 + R0;
+                unsigned char *dstbase = sC3 + (R0 * C3C + jj) * PX + 12 * g;
+                auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
+                    d0 = quant4<EXACT>(acc31[y][0], acc31[y][1], acc31[y][2], acc31[y][3], bf[0], bf[1], bf[2], bf[3], q31);
+                    d1 = quant4<EXACT>(acc32[0][y][0], acc32[0][y][1], acc32[0][y][2], acc32[0][y][3], bf[4], bf[5], bf[6], bf[7],
+                                       q32);
+                    d2 = quant4<EXACT>(acc32[1][y][0], acc32[1][y][1], acc32[1][y][2], acc32[1][y][3], bf[8], bf[9], bf[10],
+                                       bf[11], q32);
+                };
+                if (gy0 >= 0 && gy0 + 10 <= H && x0 - 1 + cb >= 0 && x0 - 1 + cb + 16 <= W) {
+                    // the wave's 10 x 16 region pixels are all inside the frame
 #pragma unroll
-                for (int y = 0; y < 10; ++y) {
-                    const int i = R0 + y;
-                    const int gy = y0 - 1 + i;
-                    unsigned d0 = quant4<EXACT>(acc31[y][0], acc31[y][1], acc31[y][2], acc31[y][3], bf[0], bf[1], bf[2], bf[3], q31);
-                    unsigned d1 = quant4<EXACT>(acc32[0][y][0], acc32[0][y][1], acc32[0][y][2], acc32[0][y][3], bf[4], bf[5],
-                                                bf[6], bf[7], q32);
-                    unsigned d2 = quant4<EXACT>(acc32[1][y][0], acc32[1][y][1], acc32[1][y][2], acc32[1][y][3], bf[8], bf[9],
-                                                bf[10], bf[11], q32);
-                    if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) d0 = d1 = d2 = 0;  // zero padding of the C4 input
-                    unsigned *dst = reinterpret_cast<unsigned *>(sC3 + (i * C3C + jj) * PX + 12 * g);
-                    dst[0] = d0;
-                    dst[1] = d1;
-                    dst[2] = d2;
+                    for (int y = 0; y < 10; ++y) {
+                        unsigned d0, d1, d2;
+                        quant_row(y, d0, d1, d2);
+                        unsigned *dst = reinterpret_cast<unsigned *>(dstbase + y * (C3C * PX));
+                        dst[0] = d0;
+                        dst[1] = d1;
+                        dst[2] = d2;
+                    }
+                } else {
+#pragma unroll
+                    for (int y = 0; y < 10; ++y) {
+                        unsigned d0, d1, d2;
+                        quant_row(y, d0, d1, d2);
+                        const int gy = gy0 + y;
+                        if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) d0 = d1 = d2 = 0;  // zero padding of the C4 input
+                        unsigned *dst = reinterpret_cast<unsigned *>(dstbase + y * (C3C * PX));
+                        dst[0] = d0;
+                        dst[1] = d1;
+                        dst[2] = d2;
+                    }
                 }
             }
             STAMP();
