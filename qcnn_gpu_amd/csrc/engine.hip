@@ -146,30 +146,32 @@ static void pack_fragments(const LayerView L[6], std::vector<int8_t> &out)
                     for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[1].at(16 * t + rho, 16 * g + j, r, s);
                 }
     // C3_1 (3x3, 48 -> 16): the B operand is a conc1 pixel in the internal channel order; k-group
-    // g < 3 byte j = internal position 16g + j; k-group 3 is zero.
+    // g byte j = internal position 16 * kb_chunk_of_kgroup(g) + j; the k-group of chunk 3 is zero.
     for (int s = 0; s < 3; ++s)
         for (int r = 0; r < 3; ++r)
             for (int lane = 0; lane < 64; ++lane) {
                 const int rho = lane & 15, g = lane >> 4;
                 int8_t *dst = &out[PackedOffsets::C3W31 + ((s * 3 + r) * 64 + lane) * 16];
-                if (g < 3)
-                    for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[3].at(rho, refch_of_pos(16 * g + j), r, s);
+                if (kb_chunk_of_kgroup(g) < 3)
+                    for (int j = 0; j < 16; ++j)
+                        dst[j] = (int8_t)L[3].at(rho, refch_of_pos(16 * kb_chunk_of_kgroup(g) + j), r, s);
             }
     // C3_2 (1x1, 48 -> 32): two 16-channel tiles.
     for (int t = 0; t < 2; ++t)
         for (int lane = 0; lane < 64; ++lane) {
             const int rho = lane & 15, g = lane >> 4;
             int8_t *dst = &out[PackedOffsets::C3W32 + (t * 64 + lane) * 16];
-            if (g < 3)
-                for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[4].at(16 * t + rho, refch_of_pos(16 * g + j), 0, 0);
+            if (kb_chunk_of_kgroup(g) < 3)
+                for (int j = 0; j < 16; ++j)
+                    dst[j] = (int8_t)L[4].at(16 * t + rho, refch_of_pos(16 * kb_chunk_of_kgroup(g) + j), 0, 0);
         }
     // C4 (3x3, 48 -> 1): fragment s; MFMA row rho < 3 is kernel row r = rho.
     for (int s = 0; s < 3; ++s)
         for (int lane = 0; lane < 64; ++lane) {
             const int rho = lane & 15, g = lane >> 4;
             int8_t *dst = &out[PackedOffsets::C4W + (s * 64 + lane) * 16];
-            if (g < 3 && rho < 3)
-                for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[5].at(0, refch_of_pos(16 * g + j), rho, s);
+            if (kb_chunk_of_kgroup(g) < 3 && rho < 3)
+                for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[5].at(0, refch_of_pos(16 * kb_chunk_of_kgroup(g) + j), rho, s);
         }
 }
 

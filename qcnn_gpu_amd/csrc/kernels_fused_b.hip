@@ -7,14 +7,17 @@
 //                         the conc2 tile n-2 (LDS), then store tile n into LDS buffer n&1;
 //   waves 4-7 (C3 waves)  run C3_1 || C3_2 + requant on the conc1 tile n-1 (LDS buffer (n-1)&1)
 //                         and write the conc2 tile n-1 into LDS buffer (n-1)&1.
-// The conc1 tile uses 64-byte pixels with the rotated chunk positions of swz() (48 bytes used), so
-// the C3 B-fragment reads are bank-conflict-free; the conc2 tile keeps dense 48-byte pixels.
+// Both LDS tiles keep dense 48-byte pixels: consecutive pixels then start 3 sixteen-byte bank slots
+// apart, so the 16 lanes of one k-group of a B-fragment read hit 16 distinct slots, and the conc1
+// tile is byte-for-byte a copy of 22 row segments of the HBM image, which lets the movers load it
+// with direct global -> LDS instructions.
 #define STAMP_ROW (wv + 8)  // diagnostic builds: rows 8..15 of the stamp buffer (kernel A owns 0..7)
 #include "fused_common.h"
 
 namespace qcnn {
 
 constexpr int TILE_ROT = 37;    // rotation of the workgroup -> tile map between rounds
+constexpr int C4_PREFETCH = 6;    // the same in the C4 stage
 constexpr int C3_PREFETCH = 6;  // B fragments requested ahead of their MFMAs in the C3 stage
 
 __device__ __forceinline__ void step_barrier_b()
@@ -46,7 +49,9 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
         const int t = n * stride + (first + n * TILE_ROT) % stride;
         return t < ntiles ? t : -1;
     };
-    const int c = lane & 15, g = lane >> 4;
+    const int g = lane >> 4;
+    const int c = kb_pixel_of_lane(lane & 15);  // column of this lane inside a wave's 16-pixel tile
+    const int gc = kb_chunk_of_kgroup(g);       // 16-byte channel chunk this lane's k-group reads
     STAMP_INIT();
 
     if (wv < 4) {
@@ -57,50 +62,76 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
         const v4i f4[3] = {w4[0], w4[64], w4[128]};
         const float b4 = a.bias_f[BIAS_OFF[5]];
         const int mul = a.rq[5].mul, shift = a.rq[5].shift;
-        const int gk = g == 3 ? 0 : g;  // conc2 pixels are dense: k-group 3 (zero weights) re-reads chunk 0
         constexpr int PIECES_ROW = INC * 3;  // 16-byte pieces per tile row
         constexpr int PIECES = INR * PIECES_ROW;
         constexpr int ITER = (PIECES + 255) / 256;
         static_assert((ITER - 1) * 256 <= PIECES, "only the last piece of a lane may fall outside the tile");
-        // piece `it` of this lane: tile-invariant global offset (relative to the tile's first
-        // halo pixel), LDS offset, and row | column << 8 | chunk << 16 for frame-edge tiles
-        int goff[ITER], soff[ITER], rpc[ITER];
+        // The conc1 tile is dense in LDS ([INR][INC][48] bytes), and so is each of its rows in HBM:
+        // piece pi = 256 it + 64 p + lane is LDS bytes 16 pi .., so one wave instruction moves 64
+        // consecutive pieces and can be a direct global -> LDS load.  Per lane and `it`: the
+        // tile-invariant global offset (relative to the tile's first halo pixel) and
+        // row | column << 8 | chunk << 16 for frame-edge tiles.
+        int goff[ITER], rpc[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int pi = it * 256 + mtid;
             const int row = pi / PIECES_ROW, rem = pi - row * PIECES_ROW;
             const int px = rem / 3, ch = rem - px * 3;
             goff[it] = (row * W + px) * 48 + ch * 16;
-            soff[it] = (row * INC + px) * 64 + swz(ch, px);
             rpc[it] = row | (px << 8) | (ch << 16);
         }
         const bool last_valid = (ITER - 1) * 256 + mtid < PIECES;
         const int cb = (p & 1) * 16, O0 = (p >> 1) * 9;  // C4: wave = 9 output rows x 16 columns
+        unsigned char ynext[9] = {}, ynext_in[9] = {};
         for (int n = 0; n <= N + 1; ++n) {
             STAMP();
-            // (1) request the conc1 tile n: rows y0-2 .. y0+TH+1, cols x0-2 .. x0+TW+1, zero outside
+            // (1) the conc1 tile n: rows y0-2 .. y0+TH+1, cols x0-2 .. x0+TW+1, zero outside the frame.
+            // A tile whose halo lies inside the frame is loaded straight into LDS buffer n&1, the
+            // load instructions threaded between the C4 MFMAs below; a frame-edge tile goes through
+            // registers (clamped addresses, branch-free) and is zeroed and stored in (3).
+            const int tl = tile_at(n);
+            unsigned char *sIn = sInBase + (n & 1) * SIN_BYTES;
+            bool direct = false;
+            const int8_t *org = a.conc1;
             v4i v[ITER];
             unsigned outside = 0;  // bit it: piece `it` lies outside the frame (zero padding of C3)
-            const int tl = tile_at(n);
             if (tl >= 0) {
                 const int f = tl / tpf, tf = tl - f * tpf;
                 const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
                 const int8_t *frame = a.conc1 + (size_t)f * a.conc_stride;
-                if (y0 >= 2 && y0 - 2 + INR <= H && x0 >= 2 && x0 - 2 + INC <= W) {  // tile + halo inside the frame
-                    const int8_t *org = frame + ((size_t)(y0 - 2) * W + (x0 - 2)) * 48;
-#pragma unroll
-                    for (int it = 0; it < ITER; ++it) {
-                        v[it] = v4i{0, 0, 0, 0};
-                        if (it + 1 < ITER || last_valid) v[it] = *reinterpret_cast<const v4i *>(org + goff[it]);
-                    }
-                } else {  // frame edge: clamped addresses, branch-free; the pieces outside are zeroed in (3)
+                direct = y0 >= 2 && y0 - 2 + INR <= H && x0 >= 2 && x0 - 2 + INC <= W;
+                if (direct) {
+                    org = frame + ((size_t)(y0 - 2) * W + (x0 - 2)) * 48;
+                } else {
 #pragma unroll
                     for (int it = 0; it < ITER; ++it) {
                         const int gy = y0 - 2 + (rpc[it] & 0xff), gx = x0 - 2 + ((rpc[it] >> 8) & 0xff);
                         const int cy = gy < 0 ? 0 : gy >= H ? H - 1 : gy, cx = gx < 0 ? 0 : gx >= W ? W - 1 : gx;
                         if (cy != gy || cx != gx) outside |= 1u << it;
                         v[it] = *reinterpret_cast<const v4i *>(frame + ((size_t)cy * W + cx) * 48 + (rpc[it] >> 16) * 16);
+                    }
+                }
+            }
+            auto request = [&](auto itc) {  // direct load of the 64 pieces this wave owns in group `it`
+                constexpr int it = decltype(itc)::value;
+                if (it + 1 < ITER || last_valid)
+                    __builtin_amdgcn_global_load_lds(org + goff[it], sIn + (it * 256 + p * 64) * 16, 16, 0, 0);
+            };
+            // the Y pixels the residual add of the NEXT step needs (tile n-1), clamped, branch-free;
+            // requested before the tile loads so that nothing younger has to land first
+            {
+                const int ty_ = tile_at(n - 1);
+                if (ty_ >= 0) {
+                    const int f = ty_ / tpf, tf = ty_ - f * tpf;
+                    const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
+                    const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
+                    const int gx = tx * TW + cb + c;
+                    const int gxc = gx < W ? gx : W - 1;
+#pragma unroll
+                    for (int y = 0; y < 9; ++y) {
+                        const int gy = ty * TH + O0 + y;
+                        ynext_in[y] = yf[(size_t)(gy < H ? gy : H - 1) * W + gxc];
                     }
                 }
             }
@@ -113,30 +144,36 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 const int f = tc / tpf, tf = tc - f * tpf;
                 const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
                 const int x0 = tx * TW, y0 = ty * TH;
-                const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
                 uint8_t *recf = a.rec + (size_t)f * a.frame_stride;
                 const unsigned char *sC3 = sC3Base + (n & 1) * SC3_BYTES;
                 const int ox = cb + c;
                 const int gx = x0 + ox;
-                const int gxc = gx < W ? gx : W - 1;
-                unsigned char ypix[9];  // residual input, requested first (clamped, branch-free)
+                unsigned char ypix[9];  // residual input: requested one step ago, landed before that step's barrier
 #pragma unroll
-                for (int y = 0; y < 9; ++y) {
-                    const int gy = y0 + O0 + y;
-                    ypix[y] = yf[(size_t)(gy < H ? gy : H - 1) * W + gxc];
-                }
-                const unsigned char *rowbase = sC3 + (O0 * C3C + cb + c) * PX + gk * 16;
+                for (int y = 0; y < 9; ++y) ypix[y] = ynext[y];
+                const unsigned char *rowbase = sC3 + (O0 * C3C + cb + c) * PX + gc * 16;  // chunk 3: zero weights
                 v4i D[11];
 #pragma unroll
                 for (int yy = 0; yy < 11; ++yy) D[yy] = v4i{0, 0, 0, 0};
+                // step I = 11 s + yy; LDS reads run C4_PREFETCH steps ahead; every third step also
+                // issues one group of the direct tile loads
+                v4i Bq[33];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-#pragma unroll
-                    for (int yy = 0; yy < 11; ++yy) {
-                        const v4i B = *reinterpret_cast<const v4i *>(rowbase + (yy * C3C + s) * PX);
-                        D[yy] = mfma16(f4[s], B, D[yy]);
+                for (int I = 0; I < C4_PREFETCH; ++I)
+                    Bq[I] = *reinterpret_cast<const v4i *>(rowbase + ((I % 11) * C3C + I / 11) * PX);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<33>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    constexpr int J = I + C4_PREFETCH;
+                    if constexpr (J < 33) Bq[J] = *reinterpret_cast<const v4i *>(rowbase + ((J % 11) * C3C + J / 11) * PX);
+                    D[I % 11] = mfma16(f4[I / 11], Bq[I], D[I % 11]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (I % 3 == 1 && I / 3 < ITER) {
+                        if (direct) request(std::integral_constant<int, I / 3>{});
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                }
+                });
+                static_assert(3 * (ITER - 1) + 1 < 33, "every load group has its C4 step");
                 STAMP();
                 if (g == 0 && ox < TW && gx < W) {
 #pragma unroll
@@ -152,11 +189,12 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                         }
                     }
                 }
+            } else if (direct) {
+                static_for<ITER>(request);
             }
             STAMP();
-            // (3) the requested tile lands in LDS buffer n&1
-            if (tl >= 0) {
-                unsigned char *sIn = sInBase + (n & 1) * SIN_BYTES;
+            // (3) a frame-edge tile lands in LDS buffer n&1
+            if (tl >= 0 && !direct) {
                 if (outside != 0) {
 #pragma unroll
                     for (int it = 0; it < ITER; ++it)
@@ -164,9 +202,13 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 }
 #pragma unroll
                 for (int it = 0; it < ITER; ++it)
-                    if (it + 1 < ITER || last_valid) *reinterpret_cast<v4i *>(sIn + soff[it]) = v[it];
+                    if (it + 1 < ITER || last_valid) *reinterpret_cast<v4i *>(sIn + (it * 256 + mtid) * 16) = v[it];
             }
             STAMP();
+            // the direct loads write LDS asynchronously: they must have landed before the barrier
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+            for (int y = 0; y < 9; ++y) ynext[y] = ynext_in[y];
             step_barrier_b();
         }
     } else {
@@ -225,20 +267,21 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 // Step I = 12 s + yy issues every MFMA that uses the B fragment of (input row yy,
                 // column shift s) and requests the fragment of step I + C3_PREFETCH; the scheduling
                 // fence after each step keeps that many LDS reads in flight ahead of their use.
-                const unsigned char *rowbase = sIn + (R0 * INC + cb + c) * 64;
+                // chunk 3 (zero weights) is the first chunk of the next pixel
+                const unsigned char *rowbase = sIn + (R0 * INC + cb + c) * PX + gc * 16;
                 const unsigned char *colbase[3];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
+                for (int s = 0; s < 3; ++s) colbase[s] = rowbase + s * PX;
                 v4i Bq[36];
 #pragma unroll
                 for (int I = 0; I < C3_PREFETCH; ++I)
-                    Bq[I] = *reinterpret_cast<const v4i *>(colbase[I / 12] + (I % 12) * (INC * 64));
+                    Bq[I] = *reinterpret_cast<const v4i *>(colbase[I / 12] + (I % 12) * (INC * PX));
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<36>([&](auto ic) {
                     constexpr int I = decltype(ic)::value;
                     constexpr int s = I / 12, yy = I % 12;
                     constexpr int J = I + C3_PREFETCH;
-                    if constexpr (J < 36) Bq[J] = *reinterpret_cast<const v4i *>(colbase[J / 12] + (J % 12) * (INC * 64));
+                    if constexpr (J < 36) Bq[J] = *reinterpret_cast<const v4i *>(colbase[J / 12] + (J % 12) * (INC * PX));
                     const v4i B = Bq[I];
                     constexpr int lo = yy - 2 > 0 ? yy - 2 : 0, hi = yy < 9 ? yy : 9;  // output rows fed
 #pragma unroll

@@ -49,7 +49,7 @@ constexpr int TH = 18, TW = 30;
 constexpr int C3R = TH + 2, C3C = 32;   // C3 output region held in LDS (halo 1)
 constexpr int INR = TH + 4, INC = 34;   // conc1 input region (halo 2)
 constexpr int PX = 48;                  // bytes per pixel of the conc2 tile (and of conc1 in HBM)
-constexpr int SIN_BYTES = INR * INC * 64;        // conc1 tile: 64-byte pixels, rotated chunks
+constexpr int SIN_BYTES = INR * INC * PX + 64;    // conc1 tile, dense (+ slack: k-group 3 reads 16 bytes past a pixel)
 constexpr int SC3_BYTES = C3R * C3C * PX + 256;  // + slack: edge lanes read 2 pixels past a row
 constexpr int LDS_BYTES = 2 * SIN_BYTES + 2 * SC3_BYTES;  // both tiles double-buffered
 static_assert(LDS_BYTES <= 160 * 1024, "kernel B exceeds the 160 KiB of LDS of one CU");
@@ -100,6 +100,18 @@ __host__ __device__ inline int pos_of_refch(int ch)
 {
     const int t = ch / 16, g = (ch % 16) / 4, i = ch % 4;
     return 12 * g + 4 * t + i;
+}
+
+// Kernel B reads its B fragments from LDS tiles with dense 48-byte pixels.  A ds_read_b128 is
+// served in groups of 16 lanes that mix 8 lanes of one MFMA k-group with 8 lanes of the next, and
+// it is conflict-free when the group covers 16 distinct 16-byte bank slots.  Pixel p, chunk k sits
+// at slot 3p + k: with k-groups (0,1,2,3) reading chunks (0,2,1,3) the two k-groups of a lane group
+// are 2 slots apart, and with the lanes 4..11 of a k-group on even pixels and the others on odd
+// pixels each half covers one parity class of slots.
+__host__ __device__ inline int kb_chunk_of_kgroup(int g) { return g == 1 ? 2 : g == 2 ? 1 : g; }
+__host__ __device__ inline int kb_pixel_of_lane(int c)  // c = lane & 15 -> column inside the wave's 16-pixel tile
+{
+    return (c >= 4 && c < 12) ? 2 * (c - 4) : c < 4 ? 2 * c + 1 : 2 * (c - 12) + 9;
 }
 
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------
