@@ -164,7 +164,8 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("height") == h and tj.get("width") == w:
-                    traffic = tj.get("k_c1c2_hbm_bytes_per_launch")
+                    # measured with frames_per_launch frames per dispatch; a dispatch of fpl frames moves fpl/that as much
+                    traffic = round(tj["k_c1c2_hbm_bytes_per_launch"] * fpl / tj.get("frames_per_launch", 1))
             except Exception:
                 traffic = None
         out = {
