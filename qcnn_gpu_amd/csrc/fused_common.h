@@ -125,6 +125,62 @@ __device__ __forceinline__ void static_range(F &&f)
 __device__ __forceinline__ int swz(int chunk, int col) { return ((chunk + (col >> 1)) & 3) * 16; }
 
 
+// Walks the tiles of one persistent workgroup.  Round n hands workgroup `first` (of `stride`) the
+// tile n * stride + (first + n * rot) % stride of the ntiles = nframes * tiles_y * tiles_x tiles
+// of a launch; the position inside a round rotates by `rot` per round (0: fixed).  The frame /
+// tile row / tile column of the tile are tracked with carries, so a step costs a handful of scalar
+// adds instead of three integer divisions.
+struct TilePos {
+    int f, ty, tx;
+    bool valid;
+};
+struct TileWalker {
+    int tiles_x, tiles_y, ntiles, stride, rot;
+    int t, r;                    // current tile, its position inside its round
+    int d[2][3];                 // (frames, tile rows, tile columns) of the two possible steps
+    TilePos pos;
+    __device__ __forceinline__ void split(int delta, int *o) const
+    {
+        const int tpf = tiles_x * tiles_y;
+        o[0] = delta / tpf;
+        const int rem = delta - o[0] * tpf;
+        o[1] = rem / tiles_x;
+        o[2] = rem - o[1] * tiles_x;
+    }
+    __device__ __forceinline__ void init(int tiles_x_, int tiles_y_, int nframes, int first, int stride_, int rot_)
+    {
+        tiles_x = tiles_x_, tiles_y = tiles_y_, stride = stride_;
+        ntiles = tiles_x * tiles_y * nframes;
+        rot = rot_ % stride;
+        t = first, r = first;
+        int o[3];
+        split(first, o);
+        pos.f = o[0], pos.ty = o[1], pos.tx = o[2];
+        pos.valid = first < ntiles;
+        split(stride + rot, d[0]);  // next round, position moved up by rot
+        split(rot, d[1]);           // next round, position wrapped: (stride + rot) - stride
+    }
+    __device__ __forceinline__ void next()  // to the tile of the next round
+    {
+        r += rot;
+        const int w = r >= stride ? 1 : 0;
+        if (w) r -= stride;
+        t += w ? rot : stride + rot;
+        pos.tx += d[w][2];
+        if (pos.tx >= tiles_x) {
+            pos.tx -= tiles_x;
+            ++pos.ty;
+        }
+        pos.ty += d[w][1];
+        if (pos.ty >= tiles_y) {
+            pos.ty -= tiles_y;
+            ++pos.f;
+        }
+        pos.f += d[w][0];
+        pos.valid = t < ntiles;
+    }
+};
+
 // Diagnostic build only (-DQCNN_STAMPS): per-wave cycle stamps of workgroup 0, written to a debug
 // buffer that nothing else reads.  Never compiled into the shipped library.
 #ifdef QCNN_STAMPS

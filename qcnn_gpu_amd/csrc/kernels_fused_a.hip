@@ -79,6 +79,8 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
     const int ntiles = tpf * a.nframes;
     const int first = blockIdx.x, stride = gridDim.x;
     const int N = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;  // tiles of this workgroup
+    TileWalker walk;  // tile first + n * stride, its frame / row / column tracked without divisions
+    walk.init(tiles_x, (H + TH - 1) / TH, a.nframes, first, stride, 0);
     STAMP_INIT();
 
     // C2 weights -> LDS, once.  They are first read after the barrier that ends step 0.
@@ -147,11 +149,9 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
             yrc[it] = row | (col << 8);
         }
         unsigned char ypre[YLOADS];
-        auto fetch_y = [&](int t) {
-            const int f = t / tpf, tf = t - f * tpf;
-            const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-            const int xa = tx * TW - 4, ya = ty * TH - 4 + PROD_ROWS * p;  // first halo pixel of this producer
-            const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
+        auto fetch_y = [&](const TilePos &tp) {
+            const int xa = tp.tx * TW - 4, ya = tp.ty * TH - 4 + PROD_ROWS * p;  // first halo pixel of this producer
+            const uint8_t *yf = a.y + (size_t)tp.f * a.frame_stride;
             if (xa >= 0 && xa + YWC <= W && ya >= 0 && ya + 9 <= H) {  // inside the frame
                 const uint8_t *org = yf + (size_t)ya * W + xa;
 #pragma unroll
@@ -170,14 +170,12 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 }
             }
         };
-        if (N > 0) fetch_y(first);
+        if (N > 0) fetch_y(walk.pos);
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n < N) {
-                const int t = first + n * stride;
-                const int tf = t % tpf;
-                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-                const int x0 = tx * TW, y0 = ty * TH;
+                const int x0 = walk.pos.tx * TW, y0 = walk.pos.ty * TH;
+                walk.next();
                 unsigned char *buf = smem + (n & 1) * SC1_BYTES;
 #pragma unroll
                 for (int it = 0; it < YLOADS; ++it) {
@@ -186,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                         for (int cc = 0; cc < 4; ++cc) sYw[ywr[it] + cc * (YCOPY - 1)] = ypre[it];
                     }
                 }
-                if (n + 1 < N) fetch_y(t + stride);  // next tile's bytes travel while this one is computed
+                if (n + 1 < N) fetch_y(walk.pos);  // next tile's bytes travel while this one is computed
                 // frame-edge tiles zero the C1 outputs that lie outside the frame (zero padding of C2)
                 const bool edge = y0 < 2 || y0 - 2 + C1R > H || x0 < 2 || x0 - 2 + C1C > W;
                 // C1 MFMAs of pixel group k: the B fragments come straight from the shifted copies
@@ -287,11 +285,9 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n >= 1) {
-                const int t = first + (n - 1) * stride;
-                const int f = t / tpf, tf = t - f * tpf;
-                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-                const int x0 = tx * TW, y0 = ty * TH;
-                int8_t *concf = a.conc1 + (size_t)f * a.conc_stride;
+                const int x0 = walk.pos.tx * TW, y0 = walk.pos.ty * TH;
+                int8_t *concf = a.conc1 + (size_t)walk.pos.f * a.conc_stride;
+                walk.next();
                 const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
                 v4i acc21[2][8], acc22[8];
 #pragma unroll

@@ -37,18 +37,15 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W;
-    const int tiles_x = (W + TW - 1) / TW;
-    const int tpf = tiles_x * ((H + TH - 1) / TH);  // tiles per frame
-    const int ntiles = tpf * a.nframes;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * a.nframes;
     const int first = blockIdx.x, stride = gridDim.x;
     const int N = (ntiles + stride - 1) / stride;  // rounds: every workgroup takes at most one tile per round
-    // Tile of this workgroup in round n (-1: none).  The position inside a round rotates by
-    // TILE_ROT per round, so no workgroup is handed a frame-edge column in every round.
-    auto tile_at = [&](int n) -> int {
-        if (n < 0 || n >= N) return -1;
-        const int t = n * stride + (first + n * TILE_ROT) % stride;
-        return t < ntiles ? t : -1;
-    };
+    // The position inside a round rotates by TILE_ROT per round, so no workgroup is handed a
+    // frame-edge column in every round.  p0 / p1 / p2 = the tiles of rounds n, n-1, n-2 in step n.
+    TileWalker walk;
+    walk.init(tiles_x, tiles_y, a.nframes, first, stride, TILE_ROT);
+    TilePos p0 = {0, 0, 0, false}, p1 = p0, p2 = p0;
     const int g = lane >> 4;
     const int c = kb_pixel_of_lane(lane & 15);  // column of this lane inside a wave's 16-pixel tile
     const int gc = kb_chunk_of_kgroup(g);       // 16-byte channel chunk this lane's k-group reads
@@ -84,22 +81,25 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
         const int cb = (p & 1) * 16, O0 = (p >> 1) * 9;  // C4: wave = 9 output rows x 16 columns
         unsigned char ynext[9] = {}, ynext_in[9] = {};
         for (int n = 0; n <= N + 1; ++n) {
+            p2 = p1;
+            p1 = p0;
+            p0 = walk.pos;
+            if (n >= N) p0.valid = false;
+            walk.next();
             STAMP();
             // (1) the conc1 tile n: rows y0-2 .. y0+TH+1, cols x0-2 .. x0+TW+1, zero outside the frame.
             // A tile whose halo lies inside the frame is loaded straight into LDS buffer n&1, the
             // load instructions threaded between the C4 MFMAs below; a frame-edge tile goes through
             // registers (clamped addresses, branch-free) and is zeroed and stored in (3).
-            const int tl = tile_at(n);
+            const bool tl = p0.valid;
             unsigned char *sIn = sInBase + (n & 1) * SIN_BYTES;
             bool direct = false;
             const int8_t *org = a.conc1;
             v4i v[ITER];
             unsigned outside = 0;  // bit it: piece `it` lies outside the frame (zero padding of C3)
-            if (tl >= 0) {
-                const int f = tl / tpf, tf = tl - f * tpf;
-                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-                const int x0 = tx * TW, y0 = ty * TH;
-                const int8_t *frame = a.conc1 + (size_t)f * a.conc_stride;
+            if (tl) {
+                const int x0 = p0.tx * TW, y0 = p0.ty * TH;
+                const int8_t *frame = a.conc1 + (size_t)p0.f * a.conc_stride;
                 direct = y0 >= 2 && y0 - 2 + INR <= H && x0 >= 2 && x0 - 2 + INC <= W;
                 if (direct) {
                     org = frame + ((size_t)(y0 - 2) * W + (x0 - 2)) * 48;
@@ -121,12 +121,10 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
             // the Y pixels the residual add of the NEXT step needs (tile n-1), clamped, branch-free;
             // requested before the tile loads so that nothing younger has to land first
             {
-                const int ty_ = tile_at(n - 1);
-                if (ty_ >= 0) {
-                    const int f = ty_ / tpf, tf = ty_ - f * tpf;
-                    const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-                    const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
-                    const int gx = tx * TW + cb + c;
+                if (p1.valid) {
+                    const int ty = p1.ty;
+                    const uint8_t *yf = a.y + (size_t)p1.f * a.frame_stride;
+                    const int gx = p1.tx * TW + cb + c;
                     const int gxc = gx < W ? gx : W - 1;
 #pragma unroll
                     for (int y = 0; y < 9; ++y) {
@@ -135,15 +133,16 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     }
                 }
             }
+            // the tile loads go out first: their issue stalls (about 100 cycles each) cost no issue
+            // slot, and they push C4 behind the C3 waves' MFMA phase, next to their VALU epilogue
+            if (direct) static_for<ITER>(request);
             STAMP();
             // (2) C4 (3x3, 48 -> 1) + applyRes_y on the conc2 tile n-2.  The three kernel rows r are
             // MFMA rows 0..2: D_yy[r][pixel] = sum_s W4[r][s] . X[yy][pixel+s], and out[y] = D_y[0] +
             // D_{y+1}[1] + D_{y+2}[2] stays inside one lane.
-            const int tc = tile_at(n - 2);
-            if (tc >= 0) {
-                const int f = tc / tpf, tf = tc - f * tpf;
-                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-                const int x0 = tx * TW, y0 = ty * TH;
+            if (p2.valid) {
+                const int f = p2.f;
+                const int x0 = p2.tx * TW, y0 = p2.ty * TH;
                 uint8_t *recf = a.rec + (size_t)f * a.frame_stride;
                 const unsigned char *sC3 = sC3Base + (n & 1) * SC3_BYTES;
                 const int ox = cb + c;
@@ -168,12 +167,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     if constexpr (J < 33) Bq[J] = *reinterpret_cast<const v4i *>(rowbase + ((J % 11) * C3C + J / 11) * PX);
                     D[I % 11] = mfma16(f4[I / 11], Bq[I], D[I % 11]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (I % 3 == 1 && I / 3 < ITER) {
-                        if (direct) request(std::integral_constant<int, I / 3>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 });
-                static_assert(3 * (ITER - 1) + 1 < 33, "every load group has its C4 step");
                 STAMP();
                 if (g == 0 && ox < TW && gx < W) {
 #pragma unroll
@@ -189,12 +183,10 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                         }
                     }
                 }
-            } else if (direct) {
-                static_for<ITER>(request);
             }
             STAMP();
             // (3) a frame-edge tile lands in LDS buffer n&1
-            if (tl >= 0 && !direct) {
+            if (tl && !direct) {
                 if (outside != 0) {
 #pragma unroll
                     for (int it = 0; it < ITER; ++it)
@@ -249,11 +241,12 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
         }
         for (int n = 0; n <= N + 1; ++n) {
             STAMP();
-            const int t = tile_at(n - 1);
-            if (t >= 0) {
-                const int tf = t % tpf;
-                const int ty = tf / tiles_x, tx = tf - ty * tiles_x;
-                const int x0 = tx * TW, y0 = ty * TH;
+            p1 = p0;
+            p0 = walk.pos;
+            if (n >= N) p0.valid = false;
+            walk.next();
+            if (p1.valid) {
+                const int x0 = p1.tx * TW, y0 = p1.ty * TH;
                 const unsigned char *sIn = sInBase + ((n - 1) & 1) * SIN_BYTES;
                 unsigned char *sC3 = sC3Base + ((n - 1) & 1) * SC3_BYTES;
                 v4i acc31[10], acc32[2][10];
