@@ -162,6 +162,35 @@ def test_full_hd_frame_bit_exact():
         assert np.array_equal(net.tap(capi.TAP_CONC2), taps_o["conc2"])
 
 
+def test_4k_frame_qp32_bit_exact():
+    """configs[3] on one GPU: a 3840x2160 Y frame, QP32, memcmp-equal with the oracle; a two-frame batch
+    through one launch gives the same bytes for both frames."""
+    qp, h, w = 32, 2160, 3840
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    anc = synth.synth_frames(h, w, qp, frames=1, seed=4)[1]
+    rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[0]))
+    lib = capi.load()
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        net.load_data(np.ascontiguousarray(anc[0]))
+        net.forward_blu()
+        rec = net.download()
+        bad = np.argwhere(rec != rec_o)
+        assert bad.size == 0, f"4K x_rec differs at {bad[:5].tolist()} ({len(bad)} pixels)"
+        d_in, d_out = C.c_void_p(), C.c_void_p()
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_in), 2 * h * w))
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_out), 2 * h * w))
+        for i in range(2):
+            capi.check(lib.qcnn_dev_h2d(C.c_void_p(d_in.value + i * h * w), anc[0].ctypes.data, h * w))
+        net.forward_blu_batch(d_in.value, d_out.value, 2, h * w)
+        net.synchronize()
+        out = np.empty((2, h, w), np.uint8)
+        capi.check(lib.qcnn_dev_d2h(out.ctypes.data, d_out, 2 * h * w))
+        assert np.array_equal(out[0], rec_o) and np.array_equal(out[1], rec_o)
+        capi.check(lib.qcnn_dev_free(d_in))
+        capi.check(lib.qcnn_dev_free(d_out))
+
+
 @pytest.mark.parametrize("group", [1, 3, 16])
 def test_batch_of_frames_any_group(group):
     """The frame loop of inference/kernel.cu:91-97 on resident frames: 7 distinct frames with a
