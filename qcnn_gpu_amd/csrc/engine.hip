@@ -344,8 +344,8 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY_E(hipMalloc(&e->bias_f, 161 * sizeof(float)));
     HIP_TRY_E(hipMalloc(&e->sse_dev, sizeof(unsigned long long)));
 #ifdef QCNN_STAMPS
-    HIP_TRY_E(hipMalloc(&e->dbg, 16 * 128 * sizeof(unsigned long long)));
-    HIP_TRY_E(hipMemset(e->dbg, 0, 16 * 128 * sizeof(unsigned long long)));
+    HIP_TRY_E(hipMalloc(&e->dbg, 24 * 128 * sizeof(unsigned long long)));
+    HIP_TRY_E(hipMemset(e->dbg, 0, 24 * 128 * sizeof(unsigned long long)));
 #endif
     for (int l = 0; l < 6; ++l) HIP_TRY_E(hipMalloc(&e->w_file[l], wsize(l)));
 #undef HIP_TRY_E
@@ -677,13 +677,13 @@ int qcnn_kernel_times_us(qcnn_t *e, double *k_c1c2_us, double *k_c3c4_us, int *p
 }
 
 #ifdef QCNN_STAMPS
-// diagnostic builds only: copies the cycle stamps (16 waves x 128 slots) of the last kernels to host
+// diagnostic builds only: copies the cycle stamps (24 rows x 128 slots) of the last kernels to host
 int qcnn_debug_stamps(qcnn_t *e, unsigned long long *host_out)
 {
     if (!e || !host_out) return fail(QCNN_E_ARG, "null argument");
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(host_out, e->dbg, 16 * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(e->dbg, 0, 16 * 128 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpy(host_out, e->dbg, 24 * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(e->dbg, 0, 24 * 128 * sizeof(unsigned long long)));
     return QCNN_OK;
 }
 #endif

@@ -16,9 +16,15 @@
 
 namespace qcnn {
 
+constexpr int C3_WAVES = 8;                       // waves 4 .. 4 + C3_WAVES - 1 run the C3 stage
+constexpr int C3_WROWS = kb::C3R / (C3_WAVES / 2);  // region rows per C3 wave (x 16 columns)
+constexpr int C3_WIN = C3_WROWS + 2;              // input rows per C3 wave
+constexpr int C3_STEPS = 3 * C3_WIN;
+constexpr int KB_THREADS = 64 * (4 + C3_WAVES);
+static_assert(C3_WROWS * (C3_WAVES / 2) == kb::C3R, "the C3 waves tile the region rows");
 constexpr int TILE_ROT = 37;    // rotation of the workgroup -> tile map between rounds
-constexpr int C4_PREFETCH = 6;    // the same in the C4 stage
-constexpr int C3_PREFETCH = 6;  // B fragments requested ahead of their MFMAs in the C3 stage
+constexpr int C4_PREFETCH = 4;    // the same in the C4 stage
+constexpr int C3_PREFETCH = 4;  // B fragments requested ahead of their MFMAs in the C3 stage
 
 __device__ __forceinline__ void step_barrier_b()
 {
@@ -26,7 +32,7 @@ __device__ __forceinline__ void step_barrier_b()
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
+__global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
 {
     using namespace kb;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -88,30 +94,16 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
             walk.next();
             STAMP();
             // (1) the conc1 tile n: rows y0-2 .. y0+TH+1, cols x0-2 .. x0+TW+1, zero outside the frame.
-            // A tile whose halo lies inside the frame is loaded straight into LDS buffer n&1, the
-            // load instructions threaded between the C4 MFMAs below; a frame-edge tile goes through
-            // registers (clamped addresses, branch-free) and is zeroed and stored in (3).
+            // A tile whose halo lies inside the frame is loaded straight into LDS buffer n&1; a
+            // frame-edge tile is handled in (3).
             const bool tl = p0.valid;
             unsigned char *sIn = sInBase + (n & 1) * SIN_BYTES;
             bool direct = false;
             const int8_t *org = a.conc1;
-            v4i v[ITER];
-            unsigned outside = 0;  // bit it: piece `it` lies outside the frame (zero padding of C3)
             if (tl) {
                 const int x0 = p0.tx * TW, y0 = p0.ty * TH;
-                const int8_t *frame = a.conc1 + (size_t)p0.f * a.conc_stride;
                 direct = y0 >= 2 && y0 - 2 + INR <= H && x0 >= 2 && x0 - 2 + INC <= W;
-                if (direct) {
-                    org = frame + ((size_t)(y0 - 2) * W + (x0 - 2)) * 48;
-                } else {
-#pragma unroll
-                    for (int it = 0; it < ITER; ++it) {
-                        const int gy = y0 - 2 + (rpc[it] & 0xff), gx = x0 - 2 + ((rpc[it] >> 8) & 0xff);
-                        const int cy = gy < 0 ? 0 : gy >= H ? H - 1 : gy, cx = gx < 0 ? 0 : gx >= W ? W - 1 : gx;
-                        if (cy != gy || cx != gx) outside |= 1u << it;
-                        v[it] = *reinterpret_cast<const v4i *>(frame + ((size_t)cy * W + cx) * 48 + (rpc[it] >> 16) * 16);
-                    }
-                }
+                org = a.conc1 + (size_t)p0.f * a.conc_stride + ((ptrdiff_t)(y0 - 2) * W + (x0 - 2)) * 48;
             }
             auto request = [&](auto itc) {  // direct load of the 64 pieces this wave owns in group `it`
                 constexpr int it = decltype(itc)::value;
@@ -185,12 +177,18 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 }
             }
             STAMP();
-            // (3) a frame-edge tile lands in LDS buffer n&1
+            // (3) a frame-edge tile goes through registers: clamped addresses (branch-free), the pieces
+            // outside the frame zeroed, then LDS buffer n&1.  Rare, so its load latency is not hidden.
             if (tl && !direct) {
-                if (outside != 0) {
+                const int x0 = p0.tx * TW, y0 = p0.ty * TH;
+                const int8_t *frame = a.conc1 + (size_t)p0.f * a.conc_stride;
+                v4i v[ITER];
 #pragma unroll
-                    for (int it = 0; it < ITER; ++it)
-                        if (outside >> it & 1) v[it] = v4i{0, 0, 0, 0};
+                for (int it = 0; it < ITER; ++it) {
+                    const int gy = y0 - 2 + (rpc[it] & 0xff), gx = x0 - 2 + ((rpc[it] >> 8) & 0xff);
+                    const int cy = gy < 0 ? 0 : gy >= H ? H - 1 : gy, cx = gx < 0 ? 0 : gx >= W ? W - 1 : gx;
+                    v[it] = *reinterpret_cast<const v4i *>(frame + ((size_t)cy * W + cx) * 48 + (rpc[it] >> 16) * 16);
+                    if (cy != gy || cx != gx) v[it] = v4i{0, 0, 0, 0};  // zero padding of C3
                 }
 #pragma unroll
                 for (int it = 0; it < ITER; ++it)
@@ -205,10 +203,10 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
         }
     } else {
         // ================================ C3 waves ================================
-        // C3_1 (3x3, 48 -> 16) and C3_2 (1x1, 48 -> 32) on the C3R x C3C region; wave = 10 region
-        // rows x 16 columns x 48 channels.  The 11 A fragments stay in registers for the whole kernel.
+        // C3_1 (3x3, 48 -> 16) and C3_2 (1x1, 48 -> 32) on the C3R x C3C region; wave = C3_WROWS region
+        // rows x 16 columns x 48 channels; two C3 waves per SIMD share the VALU in their epilogues.  The 11 A fragments stay in registers for the whole kernel.
         const int cw = wv - 4;
-        const int cb = (cw & 1) * 16, R0 = (cw >> 1) * 10;
+        const int cb = (cw & 1) * 16, R0 = (cw >> 1) * C3_WROWS;
         v4i f31[3][3], f32[2];
         {
             const v4i *w31 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C3W31) + lane;
@@ -249,15 +247,15 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 const int x0 = p1.tx * TW, y0 = p1.ty * TH;
                 const unsigned char *sIn = sInBase + ((n - 1) & 1) * SIN_BYTES;
                 unsigned char *sC3 = sC3Base + ((n - 1) & 1) * SC3_BYTES;
-                v4i acc31[10], acc32[2][10];
+                v4i acc31[C3_WROWS], acc32[2][C3_WROWS];
 #pragma unroll
-                for (int y = 0; y < 10; ++y) {
+                for (int y = 0; y < C3_WROWS; ++y) {
                     acc31[y] = b0;
                     acc32[0][y] = b1;
                     acc32[1][y] = b2;
                 }
                 // region (i, jj) <-> image (y0-1+i, x0-1+jj); tap (r, s) reads tile (i+r, jj+s).
-                // Step I = 12 s + yy issues every MFMA that uses the B fragment of (input row yy,
+                // Step I = C3_WIN s + yy issues every MFMA that uses the B fragment of (input row yy,
                 // column shift s) and requests the fragment of step I + C3_PREFETCH; the scheduling
                 // fence after each step keeps that many LDS reads in flight ahead of their use.
                 // chunk 3 (zero weights) is the first chunk of the next pixel
@@ -265,21 +263,21 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                 const unsigned char *colbase[3];
 #pragma unroll
                 for (int s = 0; s < 3; ++s) colbase[s] = rowbase + s * PX;
-                v4i Bq[36];
+                v4i Bq[C3_STEPS];
 #pragma unroll
                 for (int I = 0; I < C3_PREFETCH; ++I)
-                    Bq[I] = *reinterpret_cast<const v4i *>(colbase[I / 12] + (I % 12) * (INC * PX));
+                    Bq[I] = *reinterpret_cast<const v4i *>(colbase[I / C3_WIN] + (I % C3_WIN) * (INC * PX));
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<36>([&](auto ic) {
+                static_for<C3_STEPS>([&](auto ic) {
                     constexpr int I = decltype(ic)::value;
-                    constexpr int s = I / 12, yy = I % 12;
+                    constexpr int s = I / C3_WIN, yy = I % C3_WIN;
                     constexpr int J = I + C3_PREFETCH;
-                    if constexpr (J < 36) Bq[J] = *reinterpret_cast<const v4i *>(colbase[J / 12] + (J % 12) * (INC * PX));
+                    if constexpr (J < C3_STEPS) Bq[J] = *reinterpret_cast<const v4i *>(colbase[J / C3_WIN] + (J % C3_WIN) * (INC * PX));
                     const v4i B = Bq[I];
-                    constexpr int lo = yy - 2 > 0 ? yy - 2 : 0, hi = yy < 9 ? yy : 9;  // output rows fed
+                    constexpr int lo = yy - 2 > 0 ? yy - 2 : 0, hi = yy < C3_WROWS - 1 ? yy : C3_WROWS - 1;  // output rows fed
 #pragma unroll
                     for (int y = lo; y <= hi; ++y) acc31[y] = mfma16(f31[s][yy - y], B, acc31[y]);
-                    if constexpr (s == 1 && yy >= 1 && yy <= 10) {
+                    if constexpr (s == 1 && yy >= 1 && yy <= C3_WROWS) {
                         acc32[0][yy - 1] = mfma16(f32[0], B, acc32[0][yy - 1]);
                         acc32[1][yy - 1] = mfma16(f32[1], B, acc32[1][yy - 1]);
                     }
@@ -296,10 +294,10 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     d2 = quant4<EXACT>(acc32[1][y][0], acc32[1][y][1], acc32[1][y][2], acc32[1][y][3], bf[8], bf[9], bf[10],
                                        bf[11], q32);
                 };
-                if (gy0 >= 0 && gy0 + 10 <= H && x0 - 1 + cb >= 0 && x0 - 1 + cb + 16 <= W) {
-                    // the wave's 10 x 16 region pixels are all inside the frame
+                if (gy0 >= 0 && gy0 + C3_WROWS <= H && x0 - 1 + cb >= 0 && x0 - 1 + cb + 16 <= W) {
+                    // the wave's region pixels are all inside the frame
 #pragma unroll
-                    for (int y = 0; y < 10; ++y) {
+                    for (int y = 0; y < C3_WROWS; ++y) {
                         unsigned d0, d1, d2;
                         quant_row(y, d0, d1, d2);
                         unsigned *dst = reinterpret_cast<unsigned *>(dstbase + y * (C3C * PX));
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void k_c3c4(const FusedArgs a)
                     }
                 } else {
 #pragma unroll
-                    for (int y = 0; y < 10; ++y) {
+                    for (int y = 0; y < C3_WROWS; ++y) {
                         unsigned d0, d1, d2;
                         quant_row(y, d0, d1, d2);
                         const int gy = gy0 + y;
@@ -333,8 +331,8 @@ hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s)
     if (ntiles < 1) return hipSuccess;
     const int ncu = a.ncu > 0 ? a.ncu : 256;
     dim3 grid(ntiles < ncu ? ntiles : ncu);
-    if (exact) hipLaunchKernelGGL(k_c3c4<true>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(k_c3c4<false>, grid, dim3(512), 0, s, a);
+    if (exact) hipLaunchKernelGGL(k_c3c4<true>, grid, dim3(KB_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_c3c4<false>, grid, dim3(KB_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

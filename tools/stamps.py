@@ -19,16 +19,16 @@ net = qvrcnn(0, 1, 1, h, w)
 net.load_static_para(synth.synth_model(qp).to_nchw_vect_c_bytes())
 net.load_data(synth.synth_frames(h, w, qp)[1][0])
 lib = capi.load()
-buf = np.zeros((16, 128), np.uint64)
+buf = np.zeros((24, 128), np.uint64)
 net.set_timing(True)
 for it in range(20):
     net.forward_blu()
     net.synchronize()
     lib.qcnn_debug_stamps(net._h, buf.ctypes.data_as(C.c_void_p))
 print("kernel times (us) k_c1c2, k_c3c4, passes:", net.kernel_times_us())
-# rows 0..7: waves of kernel A (k_c1c2); rows 8..15: waves of kernel B (k_c3c4)
+# rows 0..7: waves of kernel A (k_c1c2); rows 8..: waves of kernel B (k_c3c4)
 t0 = buf[buf > 0].min()
-for wv in range(16):
+for wv in range(24):
     row = buf[wv]
     n = int((row > 0).sum())
     if n == 0:
