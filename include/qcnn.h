@@ -77,6 +77,18 @@ int qcnn_forward_blu(qcnn_t *e);
  * i*stride (stride in bytes, >= height*width).  Asynchronous on the engine stream. */
 int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride);
 
+/* The whole timed region of inference/kernel.cu:89-101 for a clip held in HOST memory: for each of
+ * `nframes` frames load_data (H2D), forward_blu, D2H of I1.x_rec.  Frame i is read from
+ * host_y + i*stride and written to host_rec + i*stride (stride in bytes, >= height*width).  Runs as
+ * a three-stream pipeline over groups of frames (see qcnn_batch_group): the H2D copy of group k+1 and
+ * the D2H copy of group k-1 overlap the kernels of group k; the caller's buffers are page-locked for
+ * the duration of the call when the runtime allows it.  Blocking: returns when host_rec is complete.
+ * If host_ori is not NULL (same stride), sse_before[i] / sse_after[i] (either may be NULL) receive the
+ * integer sums of squared differences of frame i against the original before and after the net,
+ * computed on the device: the numerators of vrcnn_data::psnr / psnr_pf (inference/yuv_data.cpp:87-112). */
+int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, int nframes, size_t stride,
+                          const uint8_t *host_ori, uint64_t *sse_before, uint64_t *sse_after);
+
 /* Frames that one kernel launch of qcnn_forward_blu_batch covers (the loop of
  * inference/kernel.cu:91-97 has no such knob: it is the price of the intermediate conc1 image,
  * 48*height*width bytes of device scratch per frame of a launch).  set > 0 changes it, current

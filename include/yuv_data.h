@@ -21,11 +21,13 @@ public:
     double psnr_pf(void);                                   /* inference/yuv_data.cpp:98-112 */
     double psnr_frame(const datatype *data, int n);         /* PSNR of frame n of `data` */
     int save_recon_as(char *filename);                      /* inference/yuv_data.cpp:113-128 */
+    static double psnr_from_sse(unsigned long long sse, long n); /* 10*log10(65025 / (sse/n)), :94-96 */
     ~vrcnn_data(void);
 
     int frame, h, w;
     long nSize;
     datatype *ori, *input, *recon;
+    bool pinned; /* the three buffers are page-locked (qcnn_host_alloc_pinned) */
 };
 
 #endif

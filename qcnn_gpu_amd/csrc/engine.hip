@@ -77,6 +77,11 @@ struct qcnn_engine {
     bool exact = false;  // true: float-pipeline kernels; false: integer fast path proved safe
     int force_exact = 0;
     Requant rq[6];
+    // clip pipeline (qcnn_forward_blu_clip): copy streams, two-deep device rings, hand-off events
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    uint8_t *ring_in[2] = {nullptr, nullptr}, *ring_out[2] = {nullptr, nullptr}, *ring_ori[2] = {nullptr, nullptr};
+    int ring_frames = 0;  // capacity of each ring slot, in frames
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // 3 per pass
@@ -368,6 +373,16 @@ int qcnn_destroy(qcnn_t *e)
     (void)hipFree(e->bias_i);
     (void)hipFree(e->bias_f);
     (void)hipFree(e->sse_dev);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(e->ring_in[b]);
+        (void)hipFree(e->ring_out[b]);
+        (void)hipFree(e->ring_ori[b]);
+        if (e->ev_in[b]) (void)hipEventDestroy(e->ev_in[b]);
+        if (e->ev_comp[b]) (void)hipEventDestroy(e->ev_comp[b]);
+        if (e->ev_out[b]) (void)hipEventDestroy(e->ev_out[b]);
+    }
+    if (e->s_in) (void)hipStreamDestroy(e->s_in);
+    if (e->s_out) (void)hipStreamDestroy(e->s_out);
     (void)hipFree(e->dbg);
     (void)hipFree(e->x_ppro);
     for (int l = 0; l < 6; ++l) {
@@ -487,6 +502,133 @@ int qcnn_batch_group(qcnn_t *e, int set, int *current)
     if (!e) return fail(QCNN_E_ARG, "null engine");
     if (set > 0) e->group = set;
     if (current) *current = e->group;
+    return QCNN_OK;
+}
+
+// Streams, events and ring slots of the clip pipeline, created on first use / grown on demand.
+static int ensure_clip(qcnn_engine *e, int frames, bool with_ori)
+{
+    HIP_TRY(hipSetDevice(e->gpu));
+    if (!e->s_in) HIP_TRY(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+    if (!e->s_out) HIP_TRY(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        if (!e->ev_in[b]) HIP_TRY(hipEventCreateWithFlags(&e->ev_in[b], hipEventDisableTiming));
+        if (!e->ev_comp[b]) HIP_TRY(hipEventCreateWithFlags(&e->ev_comp[b], hipEventDisableTiming));
+        if (!e->ev_out[b]) HIP_TRY(hipEventCreateWithFlags(&e->ev_out[b], hipEventDisableTiming));
+    }
+    if (frames > e->ring_frames) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (int b = 0; b < 2; ++b) {
+            (void)hipFree(e->ring_in[b]);
+            (void)hipFree(e->ring_out[b]);
+            (void)hipFree(e->ring_ori[b]);
+            e->ring_in[b] = e->ring_out[b] = e->ring_ori[b] = nullptr;
+        }
+        e->ring_frames = 0;
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipMalloc(&e->ring_in[b], (size_t)frames * e->HW));
+            HIP_TRY(hipMalloc(&e->ring_out[b], (size_t)frames * e->HW));
+        }
+        e->ring_frames = frames;
+    }
+    if (with_ori)
+        for (int b = 0; b < 2; ++b)
+            if (!e->ring_ori[b]) HIP_TRY(hipMalloc(&e->ring_ori[b], (size_t)e->ring_frames * e->HW));
+    return QCNN_OK;
+}
+
+int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, int nframes, size_t stride,
+                          const uint8_t *host_ori, uint64_t *sse_before, uint64_t *sse_after)
+{
+    if (!e || !host_y || !host_rec) return fail(QCNN_E_ARG, "null argument");
+    if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
+    if (nframes < 0 || stride < e->HW) return fail(QCNN_E_ARG, "bad clip: nframes=%d stride=%zu", nframes, stride);
+    if ((sse_before || sse_after) && !host_ori) return fail(QCNN_E_ARG, "SSE output without the original frames");
+    if (nframes == 0) return QCNN_OK;
+    const size_t HW = e->HW;
+    const int chunk = nframes < e->group ? nframes : e->group;
+    const bool sse = host_ori && (sse_before || sse_after);
+    int rc = ensure_clip(e, chunk, sse);
+    if (rc) return rc;
+    rc = ensure_conc(e, chunk);
+    if (rc) return rc;
+    // Page-lock the caller's buffers for the duration of the call so that the copies are true DMA and
+    // overlap the kernels.  Failure (already pinned, overlapping ranges of a sharded caller) is fine:
+    // the copies then run through the runtime's staging path.
+    const size_t span = (size_t)(nframes - 1) * stride + HW;
+    const bool reg_y = hipHostRegister(const_cast<uint8_t *>(host_y), span, hipHostRegisterDefault) == hipSuccess;
+    const bool reg_r = hipHostRegister(host_rec, span, hipHostRegisterDefault) == hipSuccess;
+    const bool reg_o = sse && hipHostRegister(const_cast<uint8_t *>(host_ori), span, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    unsigned long long *d_sse = nullptr;  // [2][nframes]: before, after
+    auto cleanup = [&]() {
+        if (reg_y) (void)hipHostUnregister(const_cast<uint8_t *>(host_y));
+        if (reg_r) (void)hipHostUnregister(host_rec);
+        if (reg_o) (void)hipHostUnregister(const_cast<uint8_t *>(host_ori));
+        (void)hipFree(d_sse);
+    };
+#define HIP_TRY_C(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipDeviceSynchronize();                                                      \
+            cleanup();                                                                         \
+            return fail(QCNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));            \
+        }                                                                                      \
+    } while (0)
+    if (sse) {
+        HIP_TRY_C(hipMalloc(&d_sse, 2 * (size_t)nframes * sizeof(unsigned long long)));
+        HIP_TRY_C(hipMemsetAsync(d_sse, 0, 2 * (size_t)nframes * sizeof(unsigned long long), e->stream));
+    }
+    for (int k = 0, i0 = 0; i0 < nframes; ++k, i0 += chunk) {
+        const int b = k & 1;
+        const int nf = nframes - i0 < chunk ? nframes - i0 : chunk;
+        // copy-in stream: slot b is free once the kernels of chunk k-2 have read it
+        HIP_TRY_C(hipStreamWaitEvent(e->s_in, e->ev_comp[b], 0));
+        HIP_TRY_C(hipMemcpy2DAsync(e->ring_in[b], HW, host_y + (size_t)i0 * stride, stride, HW, nf, hipMemcpyHostToDevice,
+                                   e->s_in));
+        if (sse)
+            HIP_TRY_C(hipMemcpy2DAsync(e->ring_ori[b], HW, host_ori + (size_t)i0 * stride, stride, HW, nf,
+                                       hipMemcpyHostToDevice, e->s_in));
+        HIP_TRY_C(hipEventRecord(e->ev_in[b], e->s_in));
+        // compute stream: needs the frames, and the output slot drained by the copy-out of chunk k-2
+        HIP_TRY_C(hipStreamWaitEvent(e->stream, e->ev_in[b], 0));
+        HIP_TRY_C(hipStreamWaitEvent(e->stream, e->ev_out[b], 0));
+        rc = launch_frames(e, e->ring_in[b], e->ring_out[b], nf, HW);
+        if (rc) {
+            (void)hipDeviceSynchronize();
+            cleanup();
+            return rc;
+        }
+        if (sse)
+            for (int f = 0; f < nf; ++f) {
+                if (sse_before)
+                    HIP_TRY_C(launch_sse_acc(e->ring_in[b] + (size_t)f * HW, e->ring_ori[b] + (size_t)f * HW, HW,
+                                             d_sse + i0 + f, e->stream));
+                if (sse_after)
+                    HIP_TRY_C(launch_sse_acc(e->ring_out[b] + (size_t)f * HW, e->ring_ori[b] + (size_t)f * HW, HW,
+                                             d_sse + nframes + i0 + f, e->stream));
+            }
+        HIP_TRY_C(hipEventRecord(e->ev_comp[b], e->stream));
+        // copy-out stream
+        HIP_TRY_C(hipStreamWaitEvent(e->s_out, e->ev_comp[b], 0));
+        HIP_TRY_C(hipMemcpy2DAsync(host_rec + (size_t)i0 * stride, stride, e->ring_out[b], HW, HW, nf, hipMemcpyDeviceToHost,
+                                   e->s_out));
+        HIP_TRY_C(hipEventRecord(e->ev_out[b], e->s_out));
+    }
+    HIP_TRY_C(hipStreamSynchronize(e->s_out));
+    HIP_TRY_C(hipStreamSynchronize(e->stream));
+    HIP_TRY_C(hipStreamSynchronize(e->s_in));
+    if (sse) {
+        std::vector<unsigned long long> h(2 * (size_t)nframes);
+        HIP_TRY_C(hipMemcpy(h.data(), d_sse, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nframes; ++i) {
+            if (sse_before) sse_before[i] = h[i];
+            if (sse_after) sse_after[i] = h[nframes + i];
+        }
+    }
+#undef HIP_TRY_C
+    cleanup();
     return QCNN_OK;
 }
 

@@ -9,6 +9,9 @@
 //   QCNN_QPS     comma list of QPs (default "22": the loop bounds of inference/kernel.cu:122)
 //   QCNN_FRAMES  frames per sequence (default 1 = FRAME, inference/mat.cuh:23)
 //   QCNN_GPUS    number of GPUs to shard frames over (default 1; frame i -> GPU i mod G)
+//   QCNN_PIPELINE=1    run the timed region through qcnn_forward_blu_clip: the same H2D / forward_blu /
+//                      D2H per frame, as a three-stream pipeline over groups of frames, and the PSNR
+//                      sums on the device
 //   QCNN_PSNR_PF=1     also print "PSNR of Frame %d:%f" per frame (inference/yuv_data.cpp:109)
 //   QCNN_SAVE_RECON=f  write the reconstruction as YUV 4:2:0 (inference/yuv_data.cpp:113-128)
 //   QCNN_CONVERT=1     run convert_model() instead (inference/kernel.cu:17-26): HWCN -> NCHW_VECT_C,
@@ -16,6 +19,7 @@
 #include <chrono>
 #include <string>
 #include <thread>
+#include <cstdint>
 #include <vector>
 
 #include <time.h>
@@ -58,13 +62,45 @@ static void worker(int gpu, int ngpu, char *model_fn, vrcnn_data *d, int frame, 
     }
 }
 
+// Pipelined variant of the worker: frames g, g+G, ... of the clip through qcnn_forward_blu_clip, the
+// per-frame sums of squared differences against the original written to sse_before / sse_after.
+static void worker_clip(int gpu, int ngpu, qvrcnn *net, vrcnn_data *d, int frame, int channel, int height, int width,
+                        uint64_t *sse_before, uint64_t *sse_after)
+{
+    const size_t fs = (size_t)channel * height * width;
+    const int mine = frame > gpu ? (frame - gpu + ngpu - 1) / ngpu : 0;
+    if (mine == 0) return;
+    std::vector<uint64_t> b(mine), a(mine);
+    check(qcnn_forward_blu_clip(net->engine, d->input + gpu * fs, d->recon + gpu * fs, mine, fs * ngpu, d->ori + gpu * fs,
+                                b.data(), a.data()));
+    for (int k = 0; k < mine; ++k) {
+        sse_before[gpu + (size_t)k * ngpu] = b[k];
+        sse_after[gpu + (size_t)k * ngpu] = a[k];
+    }
+}
+
 // stdout line, log.txt record and recon_psnr.data double of inference/kernel.cu:105-115
-static void report(vrcnn_data &d, char *input_fn, int frame, int height, int width, long long us)
+static void report(vrcnn_data &d, char *input_fn, int frame, int height, int width, long long us,
+                   const std::vector<uint64_t> *sse_before = nullptr, const std::vector<uint64_t> *sse_after = nullptr)
 {
     time_t now = time(0);
-    if (getenv("QCNN_PSNR_PF")) d.psnr_pf();
-    const double psnr1 = d.psnr(d.input);
-    const double psnr2 = d.psnr(d.recon);
+    double psnr1, psnr2;
+    if (sse_before && sse_after) {
+        // the integer sums came from the device; the same doubles as vrcnn_data::psnr / psnr_pf
+        const long hw = (long)height * width;
+        unsigned long long tb = 0, ta = 0;
+        for (int i = 0; i < frame; ++i) {
+            if (getenv("QCNN_PSNR_PF")) printf("PSNR of Frame %d:%f\n", i, vrcnn_data::psnr_from_sse((*sse_after)[i], hw));
+            tb += (*sse_before)[i];
+            ta += (*sse_after)[i];
+        }
+        psnr1 = vrcnn_data::psnr_from_sse(tb, d.nSize);
+        psnr2 = vrcnn_data::psnr_from_sse(ta, d.nSize);
+    } else {
+        if (getenv("QCNN_PSNR_PF")) d.psnr_pf();
+        psnr1 = d.psnr(d.input);
+        psnr2 = d.psnr(d.recon);
+    }
     printf("\nbefore net:PSNR=%.3f\nafter quantized net:PSNR=%.3f\ntime:%lldus\n", psnr1, psnr2, us);
     FILE *logfile = fopen("log.txt", "a+");
     if (!logfile)
@@ -91,6 +127,28 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
 {
     vrcnn_data test_data(frame, height, width);
     long long us;
+    if (getenv("QCNN_PIPELINE")) {
+        // engines and models are set up before the clock starts (inference/kernel.cu:86-90); the timed
+        // region is the pipelined frame loop on every GPU, frames sharded round-robin
+        if (ngpu < 1) ngpu = 1;
+        std::vector<qvrcnn *> nets;
+        for (int g = 0; g < ngpu; ++g) {
+            nets.push_back(new qvrcnn(g, 1, channel, height, width));
+            nets.back()->load_static_para(model_fn);
+        }
+        test_data.read_data(ori_fn, input_fn);
+        std::vector<uint64_t> sse_before(frame), sse_after(frame);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (int g = 0; g < ngpu; ++g)
+            th.emplace_back(worker_clip, g, ngpu, nets[g], &test_data, frame, channel, height, width, sse_before.data(),
+                            sse_after.data());
+        for (auto &t : th) t.join();
+        us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+        for (qvrcnn *n : nets) delete n;
+        report(test_data, input_fn, frame, height, width, us, &sse_before, &sse_after);
+        return;
+    }
     if (ngpu <= 1) {
         // set-up and model load happen before the clock starts, as in inference/kernel.cu:86-90;
         // the engine is kept across QPs (models switch by reloading, no rebuild)

@@ -7,9 +7,22 @@ vrcnn_data::vrcnn_data(int frame, int height, int width)
     this->h = height;
     this->w = width;
     this->nSize = (long)frame * height * width;
-    this->ori = new datatype[nSize];
-    this->input = new datatype[nSize];
-    this->recon = new datatype[nSize];
+    // Page-locked host memory when the runtime grants it (the frame copies are then true DMA and the
+    // pipelined clip entry point can overlap them with the kernels), ordinary memory otherwise.
+    void *p[3] = {nullptr, nullptr, nullptr};
+    pinned = true;
+    for (int i = 0; i < 3 && pinned; ++i) pinned = qcnn_host_alloc_pinned(&p[i], (size_t)nSize) == 0;
+    if (pinned) {
+        this->ori = static_cast<datatype *>(p[0]);
+        this->input = static_cast<datatype *>(p[1]);
+        this->recon = static_cast<datatype *>(p[2]);
+    } else {
+        for (int i = 0; i < 3; ++i)
+            if (p[i]) qcnn_host_free_pinned(p[i]);
+        this->ori = new datatype[nSize];
+        this->input = new datatype[nSize];
+        this->recon = new datatype[nSize];
+    }
 }
 
 int vrcnn_data::read_data(char *orifile, char *inputfile)
@@ -119,7 +132,20 @@ int vrcnn_data::save_recon_as(char *filename)
 
 vrcnn_data::~vrcnn_data(void)
 {
-    delete[] ori;
-    delete[] input;
-    delete[] recon;
+    if (pinned) {
+        qcnn_host_free_pinned(ori);
+        qcnn_host_free_pinned(input);
+        qcnn_host_free_pinned(recon);
+    } else {
+        delete[] ori;
+        delete[] input;
+        delete[] recon;
+    }
+}
+
+double vrcnn_data::psnr_from_sse(unsigned long long sse, long n)
+{
+    double mse = (double)sse;
+    mse /= (double)n;
+    return 10 * log10(65025.0 / mse);
 }

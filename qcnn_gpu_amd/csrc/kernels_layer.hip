@@ -197,6 +197,15 @@ hipError_t launch_sse(const void *a, const void *b, size_t n, unsigned long long
     return hipGetLastError();
 }
 
+// The same without clearing the sum first (the caller cleared it; several launches may add to it).
+hipError_t launch_sse_acc(const void *a, const void *b, size_t n, unsigned long long *dev_sum, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_sse, dim3(grid), dim3(256), 0, s, (const uint8_t *)a, (const uint8_t *)b, n, dev_sum);
+    return hipGetLastError();
+}
+
 // [H][W][48] internal channel order -> Conc1.conc layout [12][H][W][4] (test/tap helper).
 __global__ __launch_bounds__(256) void k_conc_to_ref(const int8_t *__restrict__ in, int8_t *__restrict__ out,
                                                      size_t hw)

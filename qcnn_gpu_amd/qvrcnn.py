@@ -101,6 +101,24 @@ class qvrcnn:
     def bind_io(self, dev_y: int, dev_rec: int) -> None:
         capi.check(self._lib.qcnn_bind_io(self._h, C.c_void_p(dev_y), C.c_void_p(dev_rec)))
 
+    def forward_blu_clip(self, frames: np.ndarray, ori: np.ndarray = None):
+        """load_data + forward_blu + download for every frame of a host clip [n][H][W] (uint8), pipelined.
+        Returns rec, or (rec, sse_before, sse_after) when the original clip is given."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.shape[0]
+        assert frames.shape[1:] == (self.height, self.width)
+        rec = np.empty_like(frames)
+        hw = self.height * self.width
+        if ori is None:
+            capi.check(self._lib.qcnn_forward_blu_clip(self._h, frames.ctypes.data, rec.ctypes.data, n, hw, None, None, None))
+            return rec
+        ori = np.ascontiguousarray(ori, dtype=np.uint8)
+        assert ori.shape == frames.shape
+        before, after = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        capi.check(self._lib.qcnn_forward_blu_clip(self._h, frames.ctypes.data, rec.ctypes.data, n, hw, ori.ctypes.data,
+                                                   before.ctypes.data, after.ctypes.data))
+        return rec, before, after
+
     def batch_group(self, set_to: int = 0) -> int:
         """Frames per kernel launch of forward_blu_batch; set_to > 0 changes it."""
         cur = C.c_int()

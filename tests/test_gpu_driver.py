@@ -65,6 +65,35 @@ def test_driver_single_qp_outputs(tmp_path):
     assert (tmp_path / "recon.yuv").stat().st_size == h * w * 3 // 2
 
 
+def test_driver_pipelined_clip_logs_per_frame_psnr(tmp_path):
+    """configs[4] in miniature: a 21-frame clip at QP27 through QCNN_PIPELINE=1 (H2D / kernels / D2H
+    overlapped, PSNR sums on the device); per-frame and whole-clip PSNR equal the oracle's doubles and the
+    blocking loop's outputs byte for byte."""
+    h, w, qp, nf = 72, 120, 27, 21
+    ori = _write_case(tmp_path, h, w, [qp], frames=nf)
+    env = {"QCNN_QPS": str(qp), "QCNN_FRAMES": str(nf), "QCNN_PSNR_PF": "1", "QCNN_SAVE_RECON": "recon.yuv"}
+    r = _run(tmp_path, h, w, dict(env, QCNN_PIPELINE="1", QCNN_BATCH_GROUP="4"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    anc = formats.read_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), nf, h, w)
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    rec_o = np.stack([c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i])) for i in range(nf)])
+    for i in range(nf):
+        assert ("PSNR of Frame %d:%f\n" % (i, c_oracle.psnr(rec_o[i], np.ascontiguousarray(ori[i])))) in r.stdout
+    m = re.search(r"\nbefore net:PSNR=([\d.]+)\nafter quantized net:PSNR=([\d.]+)\ntime:(\d+)us\n", r.stdout)
+    assert m, r.stdout
+    assert m.group(1) == "%.3f" % c_oracle.psnr(anc, ori) and m.group(2) == "%.3f" % c_oracle.psnr(rec_o, ori)
+    rec = formats.read_yuv420_luma(str(tmp_path / "recon.yuv"), nf, h, w)
+    assert np.array_equal(rec, rec_o)
+    pipelined = (tmp_path / "recon_psnr.data").read_bytes()
+    # the blocking loop of the reference gives the same record
+    (tmp_path / "recon_psnr.data").unlink()
+    r2 = _run(tmp_path, h, w, env)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert (tmp_path / "recon_psnr.data").read_bytes() == pipelined
+    strip = lambda t: re.sub(r"time:\d+us", "", t)
+    assert strip(r.stdout) == strip(r2.stdout)
+
+
 def test_driver_four_qps_and_frames_in_one_process(tmp_path):
     """configs[2] at the process level: QP 22,27,32,37 back to back, 3 frames each, appended outputs."""
     h, w, qps, frames = 96, 160, [22, 27, 32, 37], 3

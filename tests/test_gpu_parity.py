@@ -227,6 +227,26 @@ def test_batch_of_frames_any_group(group):
     capi.check(lib.qcnn_dev_free(d_out))
 
 
+@pytest.mark.parametrize("group", [1, 3, 16])
+def test_host_clip_pipeline(group):
+    """qcnn_forward_blu_clip: the H2D + forward_blu + D2H loop of inference/kernel.cu:89-101 as a pipeline,
+    with the per-frame SSE sums of vrcnn_data::psnr_pf computed on the device."""
+    qp, h, w, nf = 22, 41, 67, 8
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    ori, anc = synth.synth_frames(h, w, qp, frames=nf, seed=7)
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        net.batch_group(group)
+        rec, before, after = net.forward_blu_clip(anc, ori)
+        rec2 = net.forward_blu_clip(anc)
+    assert np.array_equal(rec, rec2)
+    for i in range(nf):
+        rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i]))
+        assert np.array_equal(rec[i], rec_o), f"frame {i}"
+        assert int(before[i]) == c_oracle.sse(np.ascontiguousarray(anc[i]), np.ascontiguousarray(ori[i]))
+        assert int(after[i]) == c_oracle.sse(rec_o, np.ascontiguousarray(ori[i]))
+
+
 def test_tile_independence_property():
     """Size-independent property: the output at a pixel depends only on its 13x13 neighbourhood, so a
     crop taken 6 pixels inside a larger frame equals the same region of the full result."""
