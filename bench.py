@@ -176,13 +176,22 @@ def main():
         ops_a = 2.0 * macs_a * hw * fpl
         achieved = ops_a / (ka_us * 1e-6) / 1e12 if ka_us > 0 else 0.0
         traffic = None
+        hbm = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("height") == h and tj.get("width") == w:
                     # measured with frames_per_launch frames per dispatch; a dispatch of fpl frames moves fpl/that as much
-                    traffic = round(tj["k_c1c2_hbm_bytes_per_launch"] * fpl / tj.get("frames_per_launch", 1))
+                    scale = fpl / tj.get("frames_per_launch", 1)
+                    traffic = round(tj["k_c1c2_hbm_bytes_per_launch"] * scale)
+                    both = (tj["k_c1c2_hbm_bytes_per_launch"] + tj["k_c3c4_hbm_bytes_per_launch"]) * scale
+                    if ka_us + kb_us > 0:
+                        gbs = both / ((ka_us + kb_us) * 1e-6) / 1e9
+                        hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                               "bytes_per_pixel_moved": round(both / (hw * fpl), 1), "bytes_per_pixel_algorithmic": 2,
+                               "note": "fabric-side bytes of both fused kernels (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/traffic.json) "
+                                       "over their summed launch time; the conc1 hand-off between the two kernels is what moves"}
             except Exception:
                 traffic = None
         out = {
@@ -203,6 +212,8 @@ def main():
                                             if ka_us + kb_us > 0 else None},
             "parity_vs_oracle": parity,
         }
+        if hbm is not None:
+            out["roofline"]["hbm"] = hbm
         if e2e is not None:
             out["pcie_inclusive_mpixels_s"] = round(e2e, 2)
             out["pcie_inclusive_pipelined_mpixels_s"] = round(e2e_clip, 2)
