@@ -77,7 +77,18 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist  # control plane only: barrier + max of the elapsed time
-        dist.init_process_group(backend="gloo")
+        # gloo announces its connections on stdout; the contract is ONE line there, so the rendezvous and
+        # the first barrier run with file descriptor 1 pointed at stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     lib = capi.load()
     ndev = C.c_int()
     capi.check(lib.qcnn_device_count(C.byref(ndev)))
