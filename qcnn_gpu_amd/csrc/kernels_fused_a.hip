@@ -7,6 +7,10 @@
 // a SIMD, so each SIMD always has one VALU-bound and one MFMA-bound instruction stream to
 // interleave.  The C1 tile is double-buffered in LDS; in step n the producers fill buffer n&1
 // with tile n while the consumers read buffer (n-1)&1; one workgroup barrier ends each step.
+// A workgroup walks its tiles DOWN a 32-pixel column of the frame: the top 4 rows of the C1 region
+// of a tile are the bottom 4 rows of the tile above it, so the producers copy them from the other
+// LDS buffer and compute 16 new rows instead of 20 (a "warm" tile; the first tile of a workgroup
+// and the top tile of a column are "cold" and compute all 20).
 #include "fused_common.h"
 
 namespace qcnn {
@@ -78,9 +82,26 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
     const int tpf = tiles_x * ((H + TH - 1) / TH);  // tiles per frame
     const int ntiles = tpf * a.nframes;
     const int first = blockIdx.x, stride = gridDim.x;
-    const int N = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;  // tiles of this workgroup
-    TileWalker walk;  // tile first + n * stride, its frame / row / column tracked without divisions
-    walk.init(tiles_x, (H + TH - 1) / TH, a.nframes, first, stride, 0);
+    // tiles in column-major order (frame, tile column, tile row); workgroup b takes the contiguous run
+    // [b * chunk, (b + 1) * chunk) of that order
+    const int tiles_y = (H + TH - 1) / TH;
+    const int chunk = (ntiles + stride - 1) / stride;
+    const int k0 = first * chunk;
+    const int N = k0 < ntiles ? (ntiles - k0 < chunk ? ntiles - k0 : chunk) : 0;  // tiles of this workgroup
+    TilePos pos;  // the tile the role below handles next
+    pos.f = k0 / tpf;
+    pos.tx = (k0 - pos.f * tpf) / tiles_y;
+    pos.ty = k0 - pos.f * tpf - pos.tx * tiles_y;
+    pos.valid = true;
+    auto advance = [&](TilePos &t) {
+        if (++t.ty == tiles_y) {
+            t.ty = 0;
+            if (++t.tx == tiles_x) {
+                t.tx = 0;
+                ++t.f;
+            }
+        }
+    };
     STAMP_INIT();
 
     // C2 weights -> LDS, once.  They are first read after the barrier that ends step 0.
@@ -119,23 +140,30 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 bf1[i] = a.bias_f[32 + 16 * h + i];
             }
         }
-        // per-lane constants of the six pixel groups k: LDS read address (k-group h = kernel rows
-        // 2h, 2h+1; rows 4, 5 sit 4 rows further), LDS write address, region coordinates
-        constexpr int NPIX = PROD_ROWS * C1C;  // 180
-        constexpr int NK = (NPIX + 31) / 32;
-        int rd[NK], wr[NK], ij[NK];
+        // per-lane constants of the pixel groups k, for a cold tile (mode 0: region rows 5p .. 5p+4,
+        // 180 pixels, 6 groups) and for a warm tile (mode 1: rows 4+4p .. 7+4p, 144 pixels, 5 groups):
+        // LDS read address (k-group h = kernel rows 2h, 2h+1; rows 4, 5 sit 4 rows further), LDS
+        // write address, region coordinates
+        constexpr int NKC = (PROD_ROWS * C1C + 31) / 32, NKW = (WARM_ROWS * C1C + 31) / 32;
+        int rd[2][NKC], wr[2][NKC], ij[2][NKC];
+        bool last_valid[2];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int qi = k * 32 + (lane & 31);
-            const int qc = qi < NPIX ? qi : NPIX - 1;
-            const int il = qc / C1C, j = qc - il * C1C;
-            const int cc = j & 3;
-            rd[k] = cc * YCOPY + (il + 2 * h) * YWS + (j - cc) + 4;
-            const int i = PROD_ROWS * p + il;
-            wr[k] = (i * C1C + j) * 64 + swz(h, j);
-            ij[k] = i | (j << 8);
+        for (int mode = 0; mode < 2; ++mode) {
+            const int rows = mode ? WARM_ROWS : PROD_ROWS, row0 = mode ? 4 + WARM_ROWS * p : PROD_ROWS * p;
+            const int npix = rows * C1C, nk = mode ? NKW : NKC;
+#pragma unroll
+            for (int k = 0; k < NKC; ++k) {
+                const int qi = k * 32 + (lane & 31);
+                const int qc = qi < npix ? qi : npix - 1;
+                const int il = qc / C1C, j = qc - il * C1C;
+                const int cc = j & 3;
+                rd[mode][k] = cc * YCOPY + (il + 2 * h) * YWS + (j - cc) + 4;
+                const int i = row0 + il;
+                wr[mode][k] = (i * C1C + j) * 64 + swz(h, j);
+                ij[mode][k] = i | (j << 8);
+            }
+            last_valid[mode] = (nk - 1) * 32 + (lane & 31) < npix;
         }
-        const bool last_valid = (NK - 1) * 32 + (lane & 31) < NPIX;
         constexpr int YLOADS = (9 * YWC + 63) / 64;  // bytes of the private Y tile per lane
         // byte `it` of this lane: offset in the frame relative to the tile's first halo pixel, LDS
         // offset in copy 0 (copy c sits c * (YCOPY - 1) further; -1: no byte), row | column << 8
@@ -149,8 +177,9 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
             yrc[it] = row | (col << 8);
         }
         unsigned char ypre[YLOADS];
-        auto fetch_y = [&](const TilePos &tp) {
-            const int xa = tp.tx * TW - 4, ya = tp.ty * TH - 4 + PROD_ROWS * p;  // first halo pixel of this producer
+        auto fetch_y = [&](const TilePos &tp, bool warm) {
+            // first halo pixel of this producer's rows
+            const int xa = tp.tx * TW - 4, ya = tp.ty * TH - 4 + (warm ? 4 + WARM_ROWS * p : PROD_ROWS * p);
             const uint8_t *yf = a.y + (size_t)tp.f * a.frame_stride;
             if (xa >= 0 && xa + YWC <= W && ya >= 0 && ya + 9 <= H) {  // inside the frame
                 const uint8_t *org = yf + (size_t)ya * W + xa;
@@ -170,12 +199,14 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 }
             }
         };
-        if (N > 0) fetch_y(walk.pos);
+        TilePos nxt = pos;  // tile n + 1 while tile n is computed
+        if (N > 0) fetch_y(pos, false);
+        advance(nxt);
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n < N) {
-                const int x0 = walk.pos.tx * TW, y0 = walk.pos.ty * TH;
-                walk.next();
+                const int x0 = pos.tx * TW, y0 = pos.ty * TH;
+                const bool warm = n > 0 && pos.ty > 0;  // the tile above was this workgroup's previous tile
                 unsigned char *buf = smem + (n & 1) * SC1_BYTES;
 #pragma unroll
                 for (int it = 0; it < YLOADS; ++it) {
@@ -184,73 +215,94 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                         for (int cc = 0; cc < 4; ++cc) sYw[ywr[it] + cc * (YCOPY - 1)] = ypre[it];
                     }
                 }
-                if (n + 1 < N) fetch_y(walk.pos);  // next tile's bytes travel while this one is computed
+                if (n + 1 < N) fetch_y(nxt, nxt.ty > 0);  // next tile's bytes travel while this one is computed
                 // frame-edge tiles zero the C1 outputs that lie outside the frame (zero padding of C2)
                 const bool edge = y0 < 2 || y0 - 2 + C1R > H || x0 < 2 || x0 - 2 + C1C > W;
-                // C1 MFMAs of pixel group k: the B fragments come straight from the shifted copies
-                auto c1_mfma = [&](int k, v16i &d0, v16i &d1) {
-                    const unsigned *src = reinterpret_cast<const unsigned *>(sYw + rd[k]);
-                    v4i B1, B2;
-                    B1.x = (int)src[0];
-                    B1.y = (int)src[1];
-                    B1.z = (int)src[YWS / 4];
-                    B1.w = (int)src[YWS / 4 + 1];
-                    B2.x = (int)src[YWS];       // 4 rows further: kernel row 4 for k-group 0
-                    B2.y = (int)src[YWS + 1];
-                    B2.z = B2.x;                // kernel row 5: zero weights
-                    B2.w = B2.y;
-                    d0 = mfma32(A00, B1, bias0);
-                    d1 = mfma32(A10, B1, bias1);
-                    d0 = mfma32(A01, B2, d0);
-                    d1 = mfma32(A11, B2, d1);
-                };
-                // requant + store of pixel group k
-                auto c1_store = [&](int k, const v16i &d0, const v16i &d1) {
-                    v4i o0, o1;
-                    if constexpr (!EXACT) {
-                        o0.x = quant4<false>(d0[0], d0[1], d0[2], d0[3], 0.f, 0.f, 0.f, 0.f, q);
-                        o0.y = quant4<false>(d0[4], d0[5], d0[6], d0[7], 0.f, 0.f, 0.f, 0.f, q);
-                        o0.z = quant4<false>(d0[8], d0[9], d0[10], d0[11], 0.f, 0.f, 0.f, 0.f, q);
-                        o0.w = quant4<false>(d0[12], d0[13], d0[14], d0[15], 0.f, 0.f, 0.f, 0.f, q);
-                        o1.x = quant4<false>(d1[0], d1[1], d1[2], d1[3], 0.f, 0.f, 0.f, 0.f, q);
-                        o1.y = quant4<false>(d1[4], d1[5], d1[6], d1[7], 0.f, 0.f, 0.f, 0.f, q);
-                        o1.z = quant4<false>(d1[8], d1[9], d1[10], d1[11], 0.f, 0.f, 0.f, 0.f, q);
-                        o1.w = quant4<false>(d1[12], d1[13], d1[14], d1[15], 0.f, 0.f, 0.f, 0.f, q);
-                    } else {
-                        o0.x = quant4<true>(d0[0], d0[1], d0[2], d0[3], bf0[0], bf0[1], bf0[2], bf0[3], q);
-                        o0.y = quant4<true>(d0[4], d0[5], d0[6], d0[7], bf0[4], bf0[5], bf0[6], bf0[7], q);
-                        o0.z = quant4<true>(d0[8], d0[9], d0[10], d0[11], bf0[8], bf0[9], bf0[10], bf0[11], q);
-                        o0.w = quant4<true>(d0[12], d0[13], d0[14], d0[15], bf0[12], bf0[13], bf0[14], bf0[15], q);
-                        o1.x = quant4<true>(d1[0], d1[1], d1[2], d1[3], bf1[0], bf1[1], bf1[2], bf1[3], q);
-                        o1.y = quant4<true>(d1[4], d1[5], d1[6], d1[7], bf1[4], bf1[5], bf1[6], bf1[7], q);
-                        o1.z = quant4<true>(d1[8], d1[9], d1[10], d1[11], bf1[8], bf1[9], bf1[10], bf1[11], q);
-                        o1.w = quant4<true>(d1[12], d1[13], d1[14], d1[15], bf1[12], bf1[13], bf1[14], bf1[15], q);
-                    }
-                    if (edge) {
-                        const int gy = y0 - 2 + (ij[k] & 0xff), gx = x0 - 2 + (ij[k] >> 8);
-                        if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) {
-                            o0 = v4i{0, 0, 0, 0};
-                            o1 = v4i{0, 0, 0, 0};
+                auto produce = [&](auto modec) {
+                    constexpr int MODE = decltype(modec)::value;
+                    constexpr int NK = MODE ? NKW : NKC;
+                    // C1 MFMAs of pixel group k: the B fragments come straight from the shifted copies
+                    auto c1_mfma = [&](int k, v16i &d0, v16i &d1) {
+                        const unsigned *src = reinterpret_cast<const unsigned *>(sYw + rd[MODE][k]);
+                        v4i B1, B2;
+                        B1.x = (int)src[0];
+                        B1.y = (int)src[1];
+                        B1.z = (int)src[YWS / 4];
+                        B1.w = (int)src[YWS / 4 + 1];
+                        B2.x = (int)src[YWS];       // 4 rows further: kernel row 4 for k-group 0
+                        B2.y = (int)src[YWS + 1];
+                        B2.z = B2.x;                // kernel row 5: zero weights
+                        B2.w = B2.y;
+                        d0 = mfma32(A00, B1, bias0);
+                        d1 = mfma32(A10, B1, bias1);
+                        d0 = mfma32(A01, B2, d0);
+                        d1 = mfma32(A11, B2, d1);
+                    };
+                    // requant + store of pixel group k
+                    auto c1_store = [&](int k, const v16i &d0, const v16i &d1) {
+                        v4i o0, o1;
+                        if constexpr (!EXACT) {
+                            o0.x = quant4<false>(d0[0], d0[1], d0[2], d0[3], 0.f, 0.f, 0.f, 0.f, q);
+                            o0.y = quant4<false>(d0[4], d0[5], d0[6], d0[7], 0.f, 0.f, 0.f, 0.f, q);
+                            o0.z = quant4<false>(d0[8], d0[9], d0[10], d0[11], 0.f, 0.f, 0.f, 0.f, q);
+                            o0.w = quant4<false>(d0[12], d0[13], d0[14], d0[15], 0.f, 0.f, 0.f, 0.f, q);
+                            o1.x = quant4<false>(d1[0], d1[1], d1[2], d1[3], 0.f, 0.f, 0.f, 0.f, q);
+                            o1.y = quant4<false>(d1[4], d1[5], d1[6], d1[7], 0.f, 0.f, 0.f, 0.f, q);
+                            o1.z = quant4<false>(d1[8], d1[9], d1[10], d1[11], 0.f, 0.f, 0.f, 0.f, q);
+                            o1.w = quant4<false>(d1[12], d1[13], d1[14], d1[15], 0.f, 0.f, 0.f, 0.f, q);
+                        } else {
+                            o0.x = quant4<true>(d0[0], d0[1], d0[2], d0[3], bf0[0], bf0[1], bf0[2], bf0[3], q);
+                            o0.y = quant4<true>(d0[4], d0[5], d0[6], d0[7], bf0[4], bf0[5], bf0[6], bf0[7], q);
+                            o0.z = quant4<true>(d0[8], d0[9], d0[10], d0[11], bf0[8], bf0[9], bf0[10], bf0[11], q);
+                            o0.w = quant4<true>(d0[12], d0[13], d0[14], d0[15], bf0[12], bf0[13], bf0[14], bf0[15], q);
+                            o1.x = quant4<true>(d1[0], d1[1], d1[2], d1[3], bf1[0], bf1[1], bf1[2], bf1[3], q);
+                            o1.y = quant4<true>(d1[4], d1[5], d1[6], d1[7], bf1[4], bf1[5], bf1[6], bf1[7], q);
+                            o1.z = quant4<true>(d1[8], d1[9], d1[10], d1[11], bf1[8], bf1[9], bf1[10], bf1[11], q);
+                            o1.w = quant4<true>(d1[12], d1[13], d1[14], d1[15], bf1[12], bf1[13], bf1[14], bf1[15], q);
                         }
-                    }
-                    if (k + 1 < NK || last_valid) {
-                        *reinterpret_cast<v4i *>(buf + wr[k]) = o0;         // channels 16h .. 16h+15
-                        *reinterpret_cast<v4i *>(buf + (wr[k] ^ 32)) = o1;  // channels 32+16h .. 32+16h+15
-                    }
+                        if (edge) {
+                            const int gy = y0 - 2 + (ij[MODE][k] & 0xff), gx = x0 - 2 + (ij[MODE][k] >> 8);
+                            if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) {
+                                o0 = v4i{0, 0, 0, 0};
+                                o1 = v4i{0, 0, 0, 0};
+                            }
+                        }
+                        if (k + 1 < NK || last_valid[MODE]) {
+                            *reinterpret_cast<v4i *>(buf + wr[MODE][k]) = o0;         // channels 16h .. 16h+15
+                            *reinterpret_cast<v4i *>(buf + (wr[MODE][k] ^ 32)) = o1;  // channels 32+16h .. 32+16h+15
+                        }
+                    };
+                    // software pipeline: the MFMAs of group k+1 are in flight while group k is requantised
+                    v16i dA0, dA1, dB0, dB1;
+                    c1_mfma(0, dA0, dA1);
+                    static_for<NK>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (k + 1 < NK) {
+                            if constexpr (k & 1) c1_mfma(k + 1, dA0, dA1);
+                            else c1_mfma(k + 1, dB0, dB1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (k & 1) c1_store(k, dB0, dB1);
+                        else c1_store(k, dA0, dA1);
+                    });
                 };
-                // software pipeline: the MFMAs of group k+1 are in flight while group k is requantised
-                v16i dA0, dA1, dB0, dB1;
-                c1_mfma(0, dA0, dA1);
-                static_for<NK>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    if constexpr (k + 1 < NK) {
-                        if constexpr (k & 1) c1_mfma(k + 1, dA0, dA1);
-                        else c1_mfma(k + 1, dB0, dB1);
+                if (warm) {
+                    // region rows 0..3 = rows 16..19 of the tile above, which sits in the other buffer: a
+                    // straight copy of 4 x 36 x 64 bytes (the chunk rotation depends on the column only)
+                    const v4i *src = reinterpret_cast<const v4i *>(smem + ((n - 1) & 1) * SC1_BYTES) + TH * C1C * 4;
+                    v4i *dst = reinterpret_cast<v4i *>(buf);
+                    constexpr int PIECES = 4 * C1C * 4;
+#pragma unroll
+                    for (int i0 = 0; i0 < PIECES; i0 += 256) {
+                        const int i = i0 + p * 64 + lane;
+                        if (i < PIECES) dst[i] = src[i];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (k & 1) c1_store(k, dB0, dB1);
-                    else c1_store(k, dA0, dA1);
-                });
+                    produce(std::integral_constant<int, 1>{});
+                } else {
+                    produce(std::integral_constant<int, 0>{});
+                }
+                pos = nxt;
+                advance(nxt);
             }
             STAMP();
             step_barrier();
@@ -285,9 +337,9 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n >= 1) {
-                const int x0 = walk.pos.tx * TW, y0 = walk.pos.ty * TH;
-                int8_t *concf = a.conc1 + (size_t)walk.pos.f * a.conc_stride;
-                walk.next();
+                const int x0 = pos.tx * TW, y0 = pos.ty * TH;
+                int8_t *concf = a.conc1 + (size_t)pos.f * a.conc_stride;
+                advance(pos);
                 const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
                 v4i acc21[2][8], acc22[8];
 #pragma unroll

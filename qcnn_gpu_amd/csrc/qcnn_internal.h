@@ -31,7 +31,8 @@ struct Requant {
 namespace ka {
 constexpr int TH = 16, TW = 32;
 constexpr int C1R = TH + 4, C1C = TW + 4;  // C1 output region held in LDS (halo 2)
-constexpr int PROD_ROWS = C1R / 4;         // C1 region rows per producer wave
+constexpr int PROD_ROWS = C1R / 4;         // C1 region rows per producer wave (cold tile: all 20 rows computed)
+constexpr int WARM_ROWS = TH / 4;          // the same for a warm tile (rows 4..19; rows 0..3 copied from the tile above)
 constexpr int YWR = PROD_ROWS + 5, YWC = TW + 8;  // private Y tile of one producer (halo 4 + 1 slack row)
 constexpr int YWS = YWC + 8;               // row stride of one LDS copy of it: 4 bytes lead-in, 4 tail
 constexpr int YCOPY = YWR * YWS;           // bytes of one copy; a producer keeps 4, shifted by 0..3 bytes
