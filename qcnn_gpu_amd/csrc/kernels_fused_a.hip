@@ -15,24 +15,28 @@
 
 namespace qcnn {
 
-// Load plan of the C2 stage of one consumer tile.  Step I = 12 s + yy issues every MFMA that uses
-// the B fragment of (input row yy, kernel column s).  The LDS reads of a tile (60 B fragments, 25
-// C2_2 and 18 C2_1 A fragments) are numbered in the order the steps first need them; need[I] is the
-// number of reads that must have been issued before step I.  The kernel issues the reads of step
-// I + C2_PREFETCH while it runs the MFMAs of step I.
+// Load plan of the C2 stage for a wave that owns ROWS output rows x 16 columns x 48 channels.  Step
+// I = IN s + yy issues every MFMA that uses the B fragment of (input row yy, kernel column s) of the
+// wave's IN = ROWS + 4 input rows.  The LDS reads (5 IN B fragments, 25 C2_2 and 18 C2_1 A fragments)
+// are numbered in the order the steps first need them; need[I] is the number of reads that must have
+// been issued before step I.  The kernel issues the reads of step I + C2_PREFETCH while it runs the
+// MFMAs of step I.
+template <int ROWS>
 struct C2Plan {
-    int kind[103];  // 0: B fragment (s, yy); 1: C2_2 A fragment (s, r); 2: C2_1 A fragment (s-1, r-1, t)
-    int a0[103], a1[103], a2[103];
-    int need[60];
-    int iB[5][12], i22[5][5], i21[3][3][2];
+    static constexpr int IN = ROWS + 4, STEPS = 5 * IN, ITEMS = STEPS + 25 + 18;
+    int kind[ITEMS];  // 0: B fragment (s, yy); 1: C2_2 A fragment (s, r); 2: C2_1 A fragment (s-1, r-1, t)
+    int a0[ITEMS], a1[ITEMS], a2[ITEMS];
+    int need[STEPS];
+    int iB[5][IN], i22[5][5], i21[3][3][2];
     int n;
 };
-constexpr C2Plan make_c2_plan()
+template <int ROWS>
+constexpr C2Plan<ROWS> make_c2_plan()
 {
-    C2Plan p{};
+    C2Plan<ROWS> p{};
     int n = 0;
     for (int s = 0; s < 5; ++s)
-        for (int yy = 0; yy < 12; ++yy) {
+        for (int yy = 0; yy < ROWS + 4; ++yy) {
             p.iB[s][yy] = n;
             p.kind[n] = 0, p.a0[n] = s, p.a1[n] = yy, ++n;
             if (yy < 5) {  // kernel row r = yy is first used here (output row 0)
@@ -44,18 +48,126 @@ constexpr C2Plan make_c2_plan()
                         p.kind[n] = 2, p.a0[n] = s - 1, p.a1[n] = yy - 1, p.a2[n] = t, ++n;
                     }
             }
-            p.need[s * 12 + yy] = n;
+            p.need[s * (ROWS + 4) + yy] = n;
         }
     p.n = n;
     return p;
 }
-constexpr C2Plan C2P = make_c2_plan();
-static_assert(C2P.n == 103, "60 B fragments + 25 + 18 A fragments");
+template <int ROWS>
+struct C2PlanOf {
+    static constexpr C2Plan<ROWS> P = make_c2_plan<ROWS>();
+    static_assert(P.n == C2Plan<ROWS>::ITEMS, "B fragments + 25 + 18 A fragments");
+};
 constexpr int C2_PREFETCH = 4;  // steps of look-ahead of the LDS reads
+template <int ROWS>
 constexpr int c2_issued(int I)  // reads issued once step I has issued its own
 {
-    return I < 0 ? C2P.need[C2_PREFETCH - 1] : C2P.need[I + C2_PREFETCH < 60 ? I + C2_PREFETCH : 59];
+    constexpr int STEPS = C2Plan<ROWS>::STEPS;
+    return I < 0 ? C2PlanOf<ROWS>::P.need[C2_PREFETCH - 1]
+                 : C2PlanOf<ROWS>::P.need[I + C2_PREFETCH < STEPS ? I + C2_PREFETCH : STEPS - 1];
 }
+
+// Per-lane constants of the C2 stage: biases of the lane's channels (int32 folded into the
+// accumulators on the integer path, float32 for the float pipeline) and the requantisers.
+struct C2Consts {
+    v4i b0, b1, b2;
+    float bf[12];
+    Requant q21, q22;
+};
+
+// C2_1 (3x3, 64 -> 32) and C2_2 (5x5, 64 -> 16) for ROWS output rows x 16 columns of the tile in `buf`
+// (rows R0 .. R0+ROWS-1, columns cb .. cb+15), 16x16x64 MFMA, then requant and the store into conc1.
+// LDS row = output row + r, LDS column = output column + s (the 3x3 taps are r-1, s-1 of the 5x5
+// window).  Lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel tile = 12 consecutive bytes
+// at position 12g of the pixel in the internal channel order.
+template <bool EXACT, int ROWS>
+__device__ __forceinline__ void c2_rows(const unsigned char *buf, int R0, int cb, int c, int g, const v4i *w22, const v4i *w21,
+                                        const C2Consts &k, int8_t *concf, int x0, int y0, int H, int W)
+{
+    using namespace ka;
+    using PO = C2PlanOf<ROWS>;  // PO::P is the plan
+    constexpr int IN = C2Plan<ROWS>::IN, STEPS = C2Plan<ROWS>::STEPS;
+    v4i acc21[2][ROWS], acc22[ROWS];
+#pragma unroll
+    for (int y = 0; y < ROWS; ++y) {
+        acc21[0][y] = k.b0;
+        acc21[1][y] = k.b1;
+        acc22[y] = k.b2;
+    }
+    const unsigned char *rowbase = buf + (R0 * C1C + cb + c) * 64;
+    const unsigned char *colbase[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
+    v4i item[C2Plan<ROWS>::ITEMS];
+    auto issue = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if constexpr (PO::P.kind[J] == 0)
+            item[J] = *reinterpret_cast<const v4i *>(colbase[PO::P.a0[J]] + PO::P.a1[J] * (C1C * 64));
+        else if constexpr (PO::P.kind[J] == 1)
+            item[J] = w22[(PO::P.a0[J] * 5 + PO::P.a1[J]) * 64];
+        else
+            item[J] = w21[((PO::P.a0[J] * 3 + PO::P.a1[J]) * 2 + PO::P.a2[J]) * 64];
+    };
+    static_range<0, c2_issued<ROWS>(-1)>(issue);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<STEPS>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int s = I / IN, yy = I % IN;
+        static_range<c2_issued<ROWS>(I - 1), c2_issued<ROWS>(I)>(issue);
+        const v4i B = item[PO::P.iB[s][yy]];
+        static_for<5>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int y = yy - r;
+            if constexpr (y >= 0 && y < ROWS) {
+                acc22[y] = mfma16(item[PO::P.i22[s][r]], B, acc22[y]);
+                if constexpr (s >= 1 && s <= 3 && r >= 1 && r <= 3) {
+                    acc21[0][y] = mfma16(item[PO::P.i21[s - 1][r - 1][0]], B, acc21[0][y]);
+                    acc21[1][y] = mfma16(item[PO::P.i21[s - 1][r - 1][1]], B, acc21[1][y]);
+                }
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    const int gx = x0 + cb + c, gy0 = y0 + R0;
+    int8_t *out = concf + ((size_t)gy0 * W + gx) * 48 + 12 * g;  // row y sits y * W * 48 further
+    const size_t row_bytes = (size_t)W * 48;
+    auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
+        d0 = quant4<EXACT>(acc21[0][y][0], acc21[0][y][1], acc21[0][y][2], acc21[0][y][3], k.bf[0], k.bf[1], k.bf[2], k.bf[3],
+                           k.q21);
+        d1 = quant4<EXACT>(acc21[1][y][0], acc21[1][y][1], acc21[1][y][2], acc21[1][y][3], k.bf[4], k.bf[5], k.bf[6], k.bf[7],
+                           k.q21);
+        d2 = quant4<EXACT>(acc22[y][0], acc22[y][1], acc22[y][2], acc22[y][3], k.bf[8], k.bf[9], k.bf[10], k.bf[11], k.q22);
+    };
+    if (gy0 + ROWS <= H && x0 + cb + 16 <= W) {  // the wave's pixels are all inside the frame
+#pragma unroll
+        for (int y = 0; y < ROWS; ++y) {
+            unsigned d0, d1, d2;
+            quant_row(y, d0, d1, d2);
+            unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+            dst[0] = d0;
+            dst[1] = d1;
+            dst[2] = d2;
+        }
+    } else {
+#pragma unroll
+        for (int y = 0; y < ROWS; ++y) {
+            unsigned d0, d1, d2;
+            quant_row(y, d0, d1, d2);
+            if (gy0 + y < H && gx < W) {
+                unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+                dst[0] = d0;
+                dst[1] = d1;
+                dst[2] = d2;
+            }
+        }
+    }
+}
+
+// Rows of a consumer's 8 x 16 block that the consumer itself computes; the PRODUCER wave on the same
+// SIMD would compute the rest after its C1 work.  Measured: with 7 the step does not get shorter (the
+// MFMA pipe and the vector issue port are shared by the two waves either way, and the producer's
+// one-row share reuses no fragment), so the consumer keeps all 8.
+constexpr int C2_CONS_ROWS = 8;
 
 // End of a pipeline step: every LDS write of this wave has landed, then the workgroup barrier.
 // (A raw s_barrier: global loads and stores in flight are deliberately not waited for.)
@@ -109,6 +221,30 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         const v4i *src = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C2W22);
         v4i *dst = reinterpret_cast<v4i *>(sW);
         for (int i = tid; i < SW_BYTES / 16; i += 512) dst[i] = src[i];
+    }
+
+    // C2 constants of this lane, used by the consumer and by the producer's share of the C2 rows
+    const int c = lane & 15, g = lane >> 4;
+    const int blk = wv & 3;  // the 8 x 16 output block of this SIMD's consumer / producer pair
+    const int cb = (blk & 1) * 16, R0 = (blk >> 1) * 8;
+    const v4i *w22 = reinterpret_cast<const v4i *>(sW) + lane;
+    const v4i *w21 = reinterpret_cast<const v4i *>(sW + (PackedOffsets::C2W21 - PackedOffsets::C2W22)) + lane;
+    C2Consts kc;
+    kc.q21 = a.rq[1], kc.q22 = a.rq[2];
+    kc.b0 = kc.b1 = kc.b2 = v4i{0, 0, 0, 0};
+    if constexpr (!EXACT) {
+        kc.b0 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[1] + 4 * g);
+        kc.b1 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[1] + 16 + 4 * g);
+        kc.b2 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[2] + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) kc.bf[i] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kc.bf[i] = a.bias_f[BIAS_OFF[1] + 4 * g + i];
+            kc.bf[4 + i] = a.bias_f[BIAS_OFF[1] + 16 + 4 * g + i];
+            kc.bf[8 + i] = a.bias_f[BIAS_OFF[2] + 4 * g + i];
+        }
     }
 
     if (wv < 4) {
@@ -199,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 }
             }
         };
-        TilePos nxt = pos;  // tile n + 1 while tile n is computed
+        TilePos nxt = pos, prev = pos;  // tiles n + 1 and n - 1 while tile n is computed
         if (N > 0) fetch_y(pos, false);
         advance(nxt);
         for (int n = 0; n <= N; ++n) {
@@ -301,6 +437,16 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 } else {
                     produce(std::integral_constant<int, 0>{});
                 }
+            }
+            STAMP();
+            // this wave's share of the C2 stage of tile n-1: the last rows of its consumer's block
+            if constexpr (C2_CONS_ROWS < 8) {
+                if (n >= 1)
+                    c2_rows<EXACT, 8 - C2_CONS_ROWS>(smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
+                                                     a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
+            }
+            if (n < N) {
+                prev = pos;
                 pos = nxt;
                 advance(nxt);
             }
@@ -309,115 +455,13 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         }
     } else {
         // =============================== consumer ===============================
-        // C2_1 (3x3, 64 -> 32) and C2_2 (5x5, 64 -> 16) on the TH x TW tile, 16x16x64 MFMA.
-        // Consumer = 8 output rows x 16 columns x 48 channels.  LDS row = output row + r, LDS column
-        // = output column + s (the 3x3 taps are r-1, s-1 of the 5x5 window).
-        const int cw = wv - 4;
-        const int c = lane & 15, g = lane >> 4;
-        const int cb = (cw & 1) * 16, R0 = (cw >> 1) * 8;
-        const v4i *w22 = reinterpret_cast<const v4i *>(sW) + lane;
-        const v4i *w21 = reinterpret_cast<const v4i *>(sW + (PackedOffsets::C2W21 - PackedOffsets::C2W22)) + lane;
-        const Requant q21 = a.rq[1], q22 = a.rq[2];
-        v4i b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
-        float bf[12];
-        if constexpr (!EXACT) {
-            b0 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[1] + 4 * g);
-            b1 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[1] + 16 + 4 * g);
-            b2 = *reinterpret_cast<const v4i *>(a.bias_i + BIAS_OFF[2] + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) bf[i] = 0.f;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf[i] = a.bias_f[BIAS_OFF[1] + 4 * g + i];
-                bf[4 + i] = a.bias_f[BIAS_OFF[1] + 16 + 4 * g + i];
-                bf[8 + i] = a.bias_f[BIAS_OFF[2] + 4 * g + i];
-            }
-        }
+        // the first C2_CONS_ROWS rows of the SIMD's 8 x 16 block of tile n-1
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n >= 1) {
-                const int x0 = pos.tx * TW, y0 = pos.ty * TH;
-                int8_t *concf = a.conc1 + (size_t)pos.f * a.conc_stride;
+                c2_rows<EXACT, C2_CONS_ROWS>(smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc,
+                                             a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW, pos.ty * TH, H, W);
                 advance(pos);
-                const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
-                v4i acc21[2][8], acc22[8];
-#pragma unroll
-                for (int y = 0; y < 8; ++y) {
-                    acc21[0][y] = b0;
-                    acc21[1][y] = b1;
-                    acc22[y] = b2;
-                }
-                const unsigned char *rowbase = buf + (R0 * C1C + cb + c) * 64;
-                const unsigned char *colbase[5];
-#pragma unroll
-                for (int s = 0; s < 5; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
-                v4i item[C2P.n];
-                auto issue = [&](auto jc) {
-                    constexpr int J = decltype(jc)::value;
-                    if constexpr (C2P.kind[J] == 0)
-                        item[J] = *reinterpret_cast<const v4i *>(colbase[C2P.a0[J]] + C2P.a1[J] * (C1C * 64));
-                    else if constexpr (C2P.kind[J] == 1)
-                        item[J] = w22[(C2P.a0[J] * 5 + C2P.a1[J]) * 64];
-                    else
-                        item[J] = w21[((C2P.a0[J] * 3 + C2P.a1[J]) * 2 + C2P.a2[J]) * 64];
-                };
-                static_range<0, c2_issued(-1)>(issue);
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<60>([&](auto ic) {
-                    constexpr int I = decltype(ic)::value;
-                    constexpr int s = I / 12, yy = I % 12;
-                    static_range<c2_issued(I - 1), c2_issued(I)>(issue);
-                    const v4i B = item[C2P.iB[s][yy]];
-                    static_for<5>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        constexpr int y = yy - r;
-                        if constexpr (y >= 0 && y < 8) {
-                            acc22[y] = mfma16(item[C2P.i22[s][r]], B, acc22[y]);
-                            if constexpr (s >= 1 && s <= 3 && r >= 1 && r <= 3) {
-                                acc21[0][y] = mfma16(item[C2P.i21[s - 1][r - 1][0]], B, acc21[0][y]);
-                                acc21[1][y] = mfma16(item[C2P.i21[s - 1][r - 1][1]], B, acc21[1][y]);
-                            }
-                        }
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                // epilogue: lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel tile = 12
-                // consecutive bytes at position 12g of the pixel in the internal channel order.
-                STAMP();
-                const int gx = x0 + cb + c, gy0 = y0 + R0;
-                int8_t *out = concf + ((size_t)gy0 * W + gx) * 48 + 12 * g;  // row y sits y * W * 48 further
-                const size_t row_bytes = (size_t)W * 48;
-                auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
-                    d0 = quant4<EXACT>(acc21[0][y][0], acc21[0][y][1], acc21[0][y][2], acc21[0][y][3], bf[0], bf[1], bf[2],
-                                       bf[3], q21);
-                    d1 = quant4<EXACT>(acc21[1][y][0], acc21[1][y][1], acc21[1][y][2], acc21[1][y][3], bf[4], bf[5], bf[6],
-                                       bf[7], q21);
-                    d2 = quant4<EXACT>(acc22[y][0], acc22[y][1], acc22[y][2], acc22[y][3], bf[8], bf[9], bf[10], bf[11], q22);
-                };
-                if (gy0 + 8 <= H && x0 + cb + 16 <= W) {  // the wave's 8 x 16 pixels are all inside the frame
-#pragma unroll
-                    for (int y = 0; y < 8; ++y) {
-                        unsigned d0, d1, d2;
-                        quant_row(y, d0, d1, d2);
-                        unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
-                        dst[0] = d0;
-                        dst[1] = d1;
-                        dst[2] = d2;
-                    }
-                } else {
-#pragma unroll
-                    for (int y = 0; y < 8; ++y) {
-                        unsigned d0, d1, d2;
-                        quant_row(y, d0, d1, d2);
-                        if (gy0 + y < H && gx < W) {
-                            unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
-                            dst[0] = d0;
-                            dst[1] = d1;
-                            dst[2] = d2;
-                        }
-                    }
-                }
             }
             STAMP();
             step_barrier();
