@@ -1,17 +1,20 @@
 // Kernel B of the fused forward pass: conc1 -> (C3_1 || C3_2) -> requant -> concat (LDS only) ->
 // C4 -> applyRes_y residual add + clamp -> I1.x_rec (see fused_common.h for the overall design).
 //
-// Persistent, wave-specialised like kernel A: one 512-thread workgroup per CU walks 18 x 30 output
-// tiles through a three-stage pipeline with one workgroup barrier per step.  In step n
-//   waves 0-3 (movers)    request the conc1 tile n from HBM into registers, run C4 + residual on
-//                         the conc2 tile n-2 (LDS), then store tile n into LDS buffer n&1;
-//   waves 4-7 (C3 waves)  run C3_1 || C3_2 + requant on the conc1 tile n-1 (LDS buffer (n-1)&1)
-//                         and write the conc2 tile n-1 into LDS buffer (n-1)&1.
-// Both LDS tiles keep dense 48-byte pixels: consecutive pixels then start 3 sixteen-byte bank slots
-// apart, so the 16 lanes of one k-group of a B-fragment read hit 16 distinct slots, and the conc1
-// tile is byte-for-byte a copy of 22 row segments of the HBM image, which lets the movers load it
-// with direct global -> LDS instructions.
-#define STAMP_ROW (wv + 8)  // diagnostic builds: rows 8..15 of the stamp buffer (kernel A owns 0..7)
+// Persistent, wave-specialised like kernel A: one 768-thread workgroup per CU (three waves per SIMD)
+// walks 18 x 30 output tiles through a three-stage pipeline with one workgroup barrier per step.  In
+// step n
+//   waves 0-3  (movers)    load the conc1 tile n from HBM straight into LDS buffer n&1 (direct
+//                          global -> LDS loads; frame-edge tiles through registers), then run C4 +
+//                          residual on the conc2 tile n-2 (LDS);
+//   waves 4-11 (C3 waves)  run C3_1 || C3_2 + requant on the conc1 tile n-1 (LDS buffer (n-1)&1),
+//                          5 region rows x 16 columns each, and write the conc2 tile n-1 into LDS
+//                          buffer (n-1)&1.
+// Both LDS tiles keep dense 48-byte pixels: the conc1 tile is byte-for-byte a copy of 22 row segments
+// of the HBM image, which is what lets the movers load it with direct global -> LDS instructions;
+// bank conflicts of the B-fragment reads are avoided by the lane -> pixel and k-group -> chunk maps
+// of qcnn_internal.h.
+#define STAMP_ROW (wv + 8)  // diagnostic builds: rows 8..19 of the stamp buffer (kernel A owns 0..7)
 #include "fused_common.h"
 
 namespace qcnn {
@@ -23,8 +26,8 @@ constexpr int C3_STEPS = 3 * C3_WIN;
 constexpr int KB_THREADS = 64 * (4 + C3_WAVES);
 static_assert(C3_WROWS * (C3_WAVES / 2) == kb::C3R, "the C3 waves tile the region rows");
 constexpr int TILE_ROT = 37;    // rotation of the workgroup -> tile map between rounds
-constexpr int C4_PREFETCH = 4;    // the same in the C4 stage
 constexpr int C3_PREFETCH = 4;  // B fragments requested ahead of their MFMAs in the C3 stage
+constexpr int C4_PREFETCH = 4;  // the same in the C4 stage
 
 __device__ __forceinline__ void step_barrier_b()
 {
