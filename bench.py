@@ -163,7 +163,7 @@ def main():
             e2e = n * hw / (time.perf_counter() - t1) / 1e6
             # the same region through the pipelined clip entry point (pinned DMA overlapping the kernels)
             # on page-locked host buffers allocated once, as a production caller would hold them
-            nclip = 64
+            nclip = 256
             p_in, p_out = C.c_void_p(), C.c_void_p()
             capi.check(lib.qcnn_host_alloc_pinned(C.byref(p_in), nclip * hw))
             capi.check(lib.qcnn_host_alloc_pinned(C.byref(p_out), nclip * hw))
