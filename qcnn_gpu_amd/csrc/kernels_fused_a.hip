@@ -58,7 +58,10 @@ struct C2PlanOf {
     static constexpr C2Plan<ROWS> P = make_c2_plan<ROWS>();
     static_assert(P.n == C2Plan<ROWS>::ITEMS, "B fragments + 25 + 18 A fragments");
 };
-constexpr int C2_PREFETCH = 4;  // steps of look-ahead of the LDS reads
+#ifndef C2_PREFETCH_N
+#define C2_PREFETCH_N 4
+#endif
+constexpr int C2_PREFETCH = C2_PREFETCH_N;  // steps of look-ahead of the LDS reads
 template <int ROWS>
 constexpr int c2_issued(int I)  // reads issued once step I has issued its own
 {

@@ -26,8 +26,14 @@ constexpr int C3_STEPS = 3 * C3_WIN;
 constexpr int KB_THREADS = 64 * (4 + C3_WAVES);
 static_assert(C3_WROWS * (C3_WAVES / 2) == kb::C3R, "the C3 waves tile the region rows");
 constexpr int TILE_ROT = 37;    // rotation of the workgroup -> tile map between rounds
-constexpr int C3_PREFETCH = 4;  // B fragments requested ahead of their MFMAs in the C3 stage
-constexpr int C4_PREFETCH = 4;  // the same in the C4 stage
+#ifndef C3_PREFETCH_N
+#define C3_PREFETCH_N 4
+#endif
+#ifndef C4_PREFETCH_N
+#define C4_PREFETCH_N 4
+#endif
+constexpr int C3_PREFETCH = C3_PREFETCH_N;  // B fragments requested ahead of their MFMAs in the C3 stage
+constexpr int C4_PREFETCH = C4_PREFETCH_N;  // the same in the C4 stage
 
 __device__ __forceinline__ void step_barrier_b()
 {
