@@ -228,7 +228,7 @@ def main():
         if e2e is not None:
             out["pcie_inclusive_mpixels_s"] = round(e2e, 2)
             out["pcie_inclusive_pipelined_mpixels_s"] = round(e2e_clip, 2)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(qp, h, w)
             except Exception as ex:  # the baseline is reported, never required for the GPU number
