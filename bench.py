@@ -57,7 +57,7 @@ def cpu_baseline(qp, h, w):
     t0 = time.perf_counter()
     float_model.forward_float(ws, bs, blu, anc[0])
     first = time.perf_counter() - t0
-    reps = max(1, min(5, int(12.0 / max(first, 1e-3))))
+    reps = max(1, min(30, int(12.0 / max(first, 1e-3))))   # about 12 s of CPU work
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
