@@ -247,6 +247,39 @@ def test_host_clip_pipeline(group):
         assert int(after[i]) == c_oracle.sse(rec_o, np.ascontiguousarray(ori[i]))
 
 
+def test_random_shapes_and_batches_against_oracle():
+    """Seeded sweep over frame sizes around the tile sizes of both kernels (16x32 and 18x30), batches of
+    1..5 frames per launch, all four QPs, both kernel variants: every output byte equals the oracle's."""
+    rng = np.random.default_rng(20250111)
+    lib = capi.load()
+    shapes = [(int(rng.integers(1, 120)), int(rng.integers(1, 200))) for _ in range(14)]
+    shapes += [(32, 64), (36, 60), (33, 65), (35, 59), (16, 31), (54, 90), (160, 64), (17, 640)]
+    for k, (h, w) in enumerate(shapes):
+        qp = (22, 27, 32, 37)[k % 4]
+        nf = 1 + k % 5
+        mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+        frames = synth.synth_frames(h, w, qp, frames=nf, seed=1000 + k)[1]
+        want = [c_oracle.forward_blu(mb, np.ascontiguousarray(frames[i])) for i in range(nf)]
+        d_in, d_out = C.c_void_p(), C.c_void_p()
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_in), nf * h * w))
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_out), nf * h * w))
+        capi.check(lib.qcnn_dev_h2d(d_in, np.ascontiguousarray(frames).ctypes.data, nf * h * w))
+        with qvrcnn(0, 1, 1, h, w) as net:
+            for exact in ((False, True) if k % 3 == 0 else (False,)):
+                net.set_exact(exact)
+                net.load_static_para(mb)
+                capi.check(lib.qcnn_dev_memset(d_out, 0x5A, nf * h * w))
+                net.forward_blu_batch(d_in.value, d_out.value, nf, h * w)
+                net.synchronize()
+                out = np.empty((nf, h, w), np.uint8)
+                capi.check(lib.qcnn_dev_d2h(out.ctypes.data, d_out, nf * h * w))
+                for i in range(nf):
+                    bad = np.argwhere(out[i] != want[i])
+                    assert bad.size == 0, f"{h}x{w} qp{qp} exact={exact} frame {i}: differs at {bad[:4].tolist()}"
+        capi.check(lib.qcnn_dev_free(d_in))
+        capi.check(lib.qcnn_dev_free(d_out))
+
+
 def test_tile_independence_property():
     """Size-independent property: the output at a pixel depends only on its 13x13 neighbourhood, so a
     crop taken 6 pixels inside a larger frame equals the same region of the full result."""
