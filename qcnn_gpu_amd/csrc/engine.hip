@@ -181,8 +181,10 @@ static void pack_fragments(const LayerView L[6], std::vector<int8_t> &out)
 }
 
 // Decides whether the integer fast path reproduces the reference's float32 pipeline for THIS
-// model: with every |acc|, |bias| and |acc + bias| below 2^24 all float operations are exact,
-// and with requant(blu) == 127 the clip-to-127 arm equals requantising min(s, blu).
+// model.  With every |acc|, |bias| and |acc + bias| below 2^23 all float operations are exact and
+// s = acc + bias is a signed 24-bit operand of the requantiser's multiply; with
+// requant(blu) == 127 the clip-to-127 arm equals requantising min(s, blu), and the saturating
+// 32-bit form s * mulk + cmulk (see requant4_int) keeps byte 3 at 127 beyond it.
 static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
 {
     for (int l = 0; l < 5; ++l) {
@@ -193,18 +195,15 @@ static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
                 for (int r = 0; r < L[l].ks; ++r)
                     for (int s = 0; s < L[l].ks; ++s) sum += std::abs(L[l].at(k, c, r, s));
             const long long b = std::llabs((long long)L[l].b[k]);
-            if (sum * in_max + b >= (1ll << 24)) return false;
+            if (sum * in_max + b >= (1ll << 23)) return false;
         }
         const Requant &q = rq[l];
-        if (q.blu < 0 || q.mul <= 0 || q.mul >= (1 << 23)) return false;
+        if (q.blu < 0 || q.mul <= 0 || q.shift > 24) return false;
         if ((long long)q.blu + q.bias >= (1ll << 23)) return false;
         const long long top = ((long long)(q.blu + q.bias) * q.mul) >> q.shift;
-        if (top != 127) return false;
-        if ((long long)(q.blu + q.bias) * q.mul >= (1ll << 31)) return false;
-        // pre-shifted form used by the kernels: 24-bit multiplier, product below 2^32
-        const int k = (q.shift <= 16 ? 16 : 24) - q.shift;
-        if (((long long)q.mul << k) >= (1ll << 23)) return false;
-        if (((long long)(q.blu + q.bias) * q.mul << k) >= (1ll << 32)) return false;
+        if (top != 127) return false;  // also bounds (blu + bias) * mulk below 128 << 24 = 2^31
+        // pre-shifted multiplier: a positive signed 24-bit operand; cmulk = bias * mul << k <= 2^23
+        if (((long long)q.mul << (24 - q.shift)) >= (1ll << 23)) return false;
     }
     return true;
 }

@@ -38,22 +38,6 @@ __device__ __forceinline__ v16i mfma32(v4i a, v4i b, v16i c)
     return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
 }
 
-// Integer requantiser, valid when the host-side proof holds (see engine.hip, prove_integer_path):
-// s is acc + bias, exactly what the reference's float u holds.  Both clip arms are one v_med3
-// (requant(blu) == 127 is part of the proof), and mul/cmul are pre-shifted on the host so that
-// the quotient ((v + bias) * mul) >> shift is a whole byte (byte 2 or 3) of the 32-bit product:
-// the shift is then done by the byte-permute that packs four channels into a dword.
-// The clamp is written as the median identity max(min(x, 0), min(max(x, 0), hi)), which the
-// compiler selects as one v_med3_i32 (a plain min(max(x, 0), hi) with a non-constant bound becomes
-// two instructions).
-__device__ __forceinline__ int med3i(int x, int hi)
-{
-    return max(min(x, 0), min(max(x, 0), hi));
-}
-__device__ __forceinline__ unsigned requant_prod(int s, const Requant &q)
-{
-    return __umul24((unsigned)med3i(s, q.blu), (unsigned)q.mulk) + (unsigned)q.cmulk;
-}
 // Literal float32 pipeline of ConvForward_static + CHW2CHW_VECT_C_QUANT_BLU.
 __device__ __forceinline__ int requant_float(int acc, float bf, const Requant &q)
 {
@@ -63,33 +47,130 @@ __device__ __forceinline__ int requant_float(int acc, float bf, const Requant &q
     return (int)((unsigned)((int)t + q.bias) * (unsigned)q.mul) >> q.shift;
 }
 
-__device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
+// Integer requantiser of four consecutive channels, valid when the host-side proof holds (see
+// engine.hip, prove_integer_path).  s = acc + bias is exactly what the reference's float u holds
+// and fits 24 signed bits; mul and bias * mul are pre-shifted on the host by 24 - shift, so the
+// quotient ((s + bias) * mul) >> shift is byte 3 of t = s * mulk + cmulk.  Two instructions per
+// channel:
+//   t = saturate_i32(s * mulk + cmulk)       v_mad_i32_i24 ... clamp
+//       s > blu : t >= requant(blu) << 24 = 127 << 24, and saturation keeps byte 3 at 127;
+//       s < 0   : t < 2^23, so byte 3 is 0 or negative
+//   byte j of the dword = max(sext(t[31:24]), 0)   v_max_i32 with sub-dword source and destination
+// which is both clip arms of the reference and its store-to-char truncation.  A sub-dword write
+// must not be followed directly by a vector instruction that reads the register (one wait state):
+// inside the block the next channel's multiply separates the writes, an s_nop ends it.
+__device__ __forceinline__ unsigned requant4_int(int s0, int s1, int s2, int s3, const Requant &q)
 {
-    // low bytes of a,b,c,d -> one dword (the store-to-char truncation of the reference)
-    const unsigned lo = __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x0c0c0400u);
-    const unsigned hi = __builtin_amdgcn_perm((unsigned)d, (unsigned)c, 0x0c0c0400u);
-    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    unsigned p;
+    int t;
+    asm("v_mad_i32_i24 %1, %2, %6, %7 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %1, %3, %6, %7 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %1, %4, %6, %7 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %1, %5, %6, %7 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(p), "=&v"(t)
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(q.mulk), "v"(q.cmulk));
+    return p;
 }
 
-// Requantises two consecutive channels (accumulators a0, a1; float biases only used by the EXACT
-// variant) into the low half of a dword; join2 makes a dword of four channels from two halves.
-template <bool EXACT>
-__device__ __forceinline__ unsigned quant2(int a0, int a1, float b0, float b1, const Requant &q)
+// The same for three dwords at once (the 12 channels a lane owns in the C2 and C3 epilogues; the first
+// two dwords share a requantiser): the three dependency chains are interleaved, so no instruction
+// waits for the one before it.
+__device__ __forceinline__ void requant12_int(const v4i &a, const v4i &b, const v4i &c, const Requant &qab, const Requant &qc,
+                                              unsigned &pa, unsigned &pb, unsigned &pc)
 {
-    if constexpr (EXACT)
-        return __builtin_amdgcn_perm((unsigned)requant_float(a1, b1, q), (unsigned)requant_float(a0, b0, q), 0x0c0c0400u);
-    else
-        return __builtin_amdgcn_perm(requant_prod(a1, q), requant_prod(a0, q), q.sel2);
+    int ta, tb, tc;
+    asm("v_mad_i32_i24 %3, %6, %18, %19 clamp\n\t"
+        "v_mad_i32_i24 %4, %10, %20, %21 clamp\n\t"
+        "v_mad_i32_i24 %5, %14, %22, %23 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %3, %7, %18, %19 clamp\n\t"
+        "v_mad_i32_i24 %4, %11, %20, %21 clamp\n\t"
+        "v_mad_i32_i24 %5, %15, %22, %23 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %3, %8, %18, %19 clamp\n\t"
+        "v_mad_i32_i24 %4, %12, %20, %21 clamp\n\t"
+        "v_mad_i32_i24 %5, %16, %22, %23 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %3, %9, %18, %19 clamp\n\t"
+        "v_mad_i32_i24 %4, %13, %20, %21 clamp\n\t"
+        "v_mad_i32_i24 %5, %17, %22, %23 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(pa), "=&v"(pb), "=&v"(pc), "=&v"(ta), "=&v"(tb), "=&v"(tc)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+          "v"(qab.mulk), "v"(qab.cmulk), "v"(qab.mulk), "v"(qab.cmulk), "v"(qc.mulk), "v"(qc.cmulk));
 }
-__device__ __forceinline__ unsigned join2(unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
 
-// Requantises four consecutive channels and packs them into one dword (the store-to-char
-// truncation of the reference).
+// The same for the 16 channels of one 32x32 accumulator (four dwords, one requantiser).
+__device__ __forceinline__ v4i requant16_int(const v16i &d, const Requant &q)
+{
+    unsigned p0, p1, p2, p3;
+    int t0, t1, t2, t3;
+    asm("v_mad_i32_i24 %4, %8, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %5, %12, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %6, %16, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %7, %20, %24, %25 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %3, sext(%7), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %4, %9, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %5, %13, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %6, %17, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %7, %21, %24, %25 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %3, sext(%7), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %4, %10, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %5, %14, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %6, %18, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %7, %22, %24, %25 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %3, sext(%7), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_i32_i24 %4, %11, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %5, %15, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %6, %19, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %7, %23, %24, %25 clamp\n\t"
+        "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_max_i32_sdwa %3, sext(%7), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]), "v"(d[9]), "v"(d[10]),
+          "v"(d[11]), "v"(d[12]), "v"(d[13]), "v"(d[14]), "v"(d[15]), "v"(q.mulk), "v"(q.cmulk));
+    return v4i{(int)p0, (int)p1, (int)p2, (int)p3};
+}
+
+// Requantises four consecutive channels (accumulators a0..a3; the float biases are only used by
+// the EXACT variant) and packs them into one dword.
 template <bool EXACT>
 __device__ __forceinline__ unsigned quant4(int a0, int a1, int a2, int a3, float b0, float b1, float b2, float b3,
                                            const Requant &q)
 {
-    return join2(quant2<EXACT>(a2, a3, b2, b3, q), quant2<EXACT>(a0, a1, b0, b1, q));
+    if constexpr (EXACT) {
+        const unsigned lo = __builtin_amdgcn_perm((unsigned)requant_float(a1, b1, q), (unsigned)requant_float(a0, b0, q), 0x0c0c0400u);
+        const unsigned hi = __builtin_amdgcn_perm((unsigned)requant_float(a3, b3, q), (unsigned)requant_float(a2, b2, q), 0x0c0c0400u);
+        return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    } else {
+        return requant4_int(a0, a1, a2, a3, q);
+    }
 }
 
 // Calls f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>) in order: a loop

@@ -62,12 +62,21 @@ struct C2PlanOf {
 #define C2_PREFETCH_N 4
 #endif
 constexpr int C2_PREFETCH = C2_PREFETCH_N;  // steps of look-ahead of the LDS reads
+#ifndef C2_PREFETCH_START_N
+#define C2_PREFETCH_START_N 6
+#endif
+// The reads of the first C2_PREFETCH_START steps are issued before the stage's first MFMA (the caller
+// puts other work between them and the MFMAs, so they have landed by then).
+constexpr int C2_PREFETCH_START = C2_PREFETCH_START_N;
+static_assert(C2_PREFETCH_START >= C2_PREFETCH, "the start covers at least the steady look-ahead");
 template <int ROWS>
-constexpr int c2_issued(int I)  // reads issued once step I has issued its own
+constexpr int c2_issued(int I)  // reads issued once step I has issued its own (I = -1: before step 0)
 {
     constexpr int STEPS = C2Plan<ROWS>::STEPS;
-    return I < 0 ? C2PlanOf<ROWS>::P.need[C2_PREFETCH - 1]
-                 : C2PlanOf<ROWS>::P.need[I + C2_PREFETCH < STEPS ? I + C2_PREFETCH : STEPS - 1];
+    const int start = C2PlanOf<ROWS>::P.need[C2_PREFETCH_START - 1];
+    if (I < 0) return start;
+    const int n = C2PlanOf<ROWS>::P.need[I + C2_PREFETCH < STEPS ? I + C2_PREFETCH : STEPS - 1];
+    return n > start ? n : start;
 }
 
 // Per-lane constants of the C2 stage: biases of the lane's channels (int32 folded into the
@@ -76,70 +85,44 @@ struct C2Consts {
     v4i b0, b1, b2;
     float bf[12];
     Requant q21, q22;
+#ifdef QCNN_STAMPS
+    unsigned long long *dbg;
+    int dbg_block, row, *idx;
+#endif
+};
+#ifdef QCNN_STAMPS
+#define C2_STAMP() stamp(k.dbg, k.dbg_block, k.row, *k.idx)
+#else
+#define C2_STAMP() do { } while (0)
+#endif
+
+// Accumulators of the C2 stage of one wave: ROWS output rows x 16 columns x 48 channels.
+template <int ROWS>
+struct C2Acc {
+    v4i a21[2][ROWS], a22[ROWS];
 };
 
-// C2_1 (3x3, 64 -> 32) and C2_2 (5x5, 64 -> 16) for ROWS output rows x 16 columns of the tile in `buf`
-// (rows R0 .. R0+ROWS-1, columns cb .. cb+15), 16x16x64 MFMA, then requant and the store into conc1.
-// LDS row = output row + r, LDS column = output column + s (the 3x3 taps are r-1, s-1 of the 5x5
-// window).  Lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel tile = 12 consecutive bytes
-// at position 12g of the pixel in the internal channel order.
+// Requant of the accumulators and the store into conc1 (frame `concf`): rows R0 .. R0+ROWS-1, columns
+// cb .. cb+15 of the tile at (x0, y0).  Lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel
+// tile = 12 consecutive bytes at position 12g of the pixel in the internal channel order.
 template <bool EXACT, int ROWS>
-__device__ __forceinline__ void c2_rows(const unsigned char *buf, int R0, int cb, int c, int g, const v4i *w22, const v4i *w21,
-                                        const C2Consts &k, int8_t *concf, int x0, int y0, int H, int W)
+__device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb, int c, int g, const C2Consts &k, int8_t *concf,
+                                         int x0, int y0, int H, int W)
 {
-    using namespace ka;
-    using PO = C2PlanOf<ROWS>;  // PO::P is the plan
-    constexpr int IN = C2Plan<ROWS>::IN, STEPS = C2Plan<ROWS>::STEPS;
-    v4i acc21[2][ROWS], acc22[ROWS];
-#pragma unroll
-    for (int y = 0; y < ROWS; ++y) {
-        acc21[0][y] = k.b0;
-        acc21[1][y] = k.b1;
-        acc22[y] = k.b2;
-    }
-    const unsigned char *rowbase = buf + (R0 * C1C + cb + c) * 64;
-    const unsigned char *colbase[5];
-#pragma unroll
-    for (int s = 0; s < 5; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
-    v4i item[C2Plan<ROWS>::ITEMS];
-    auto issue = [&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        if constexpr (PO::P.kind[J] == 0)
-            item[J] = *reinterpret_cast<const v4i *>(colbase[PO::P.a0[J]] + PO::P.a1[J] * (C1C * 64));
-        else if constexpr (PO::P.kind[J] == 1)
-            item[J] = w22[(PO::P.a0[J] * 5 + PO::P.a1[J]) * 64];
-        else
-            item[J] = w21[((PO::P.a0[J] * 3 + PO::P.a1[J]) * 2 + PO::P.a2[J]) * 64];
-    };
-    static_range<0, c2_issued<ROWS>(-1)>(issue);
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<STEPS>([&](auto ic) {
-        constexpr int I = decltype(ic)::value;
-        constexpr int s = I / IN, yy = I % IN;
-        static_range<c2_issued<ROWS>(I - 1), c2_issued<ROWS>(I)>(issue);
-        const v4i B = item[PO::P.iB[s][yy]];
-        static_for<5>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            constexpr int y = yy - r;
-            if constexpr (y >= 0 && y < ROWS) {
-                acc22[y] = mfma16(item[PO::P.i22[s][r]], B, acc22[y]);
-                if constexpr (s >= 1 && s <= 3 && r >= 1 && r <= 3) {
-                    acc21[0][y] = mfma16(item[PO::P.i21[s - 1][r - 1][0]], B, acc21[0][y]);
-                    acc21[1][y] = mfma16(item[PO::P.i21[s - 1][r - 1][1]], B, acc21[1][y]);
-                }
-            }
-        });
-        __builtin_amdgcn_sched_barrier(0);
-    });
     const int gx = x0 + cb + c, gy0 = y0 + R0;
     int8_t *out = concf + ((size_t)gy0 * W + gx) * 48 + 12 * g;  // row y sits y * W * 48 further
     const size_t row_bytes = (size_t)W * 48;
     auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
-        d0 = quant4<EXACT>(acc21[0][y][0], acc21[0][y][1], acc21[0][y][2], acc21[0][y][3], k.bf[0], k.bf[1], k.bf[2], k.bf[3],
-                           k.q21);
-        d1 = quant4<EXACT>(acc21[1][y][0], acc21[1][y][1], acc21[1][y][2], acc21[1][y][3], k.bf[4], k.bf[5], k.bf[6], k.bf[7],
-                           k.q21);
-        d2 = quant4<EXACT>(acc22[y][0], acc22[y][1], acc22[y][2], acc22[y][3], k.bf[8], k.bf[9], k.bf[10], k.bf[11], k.q22);
+        if constexpr (!EXACT) {
+            requant12_int(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, d0, d1, d2);
+        } else {
+            d0 = quant4<EXACT>(acc.a21[0][y][0], acc.a21[0][y][1], acc.a21[0][y][2], acc.a21[0][y][3], k.bf[0], k.bf[1], k.bf[2],
+                               k.bf[3], k.q21);
+            d1 = quant4<EXACT>(acc.a21[1][y][0], acc.a21[1][y][1], acc.a21[1][y][2], acc.a21[1][y][3], k.bf[4], k.bf[5], k.bf[6],
+                               k.bf[7], k.q21);
+            d2 = quant4<EXACT>(acc.a22[y][0], acc.a22[y][1], acc.a22[y][2], acc.a22[y][3], k.bf[8], k.bf[9], k.bf[10], k.bf[11],
+                               k.q22);
+        }
     };
     if (gy0 + ROWS <= H && x0 + cb + 16 <= W) {  // the wave's pixels are all inside the frame
 #pragma unroll
@@ -166,11 +149,72 @@ __device__ __forceinline__ void c2_rows(const unsigned char *buf, int R0, int cb
     }
 }
 
+// C2_1 (3x3, 64 -> 32) and C2_2 (5x5, 64 -> 16) for ROWS output rows x 16 columns of the tile in `buf`
+// (rows R0 .. R0+ROWS-1, columns cb .. cb+15) as 16x16x64 MFMAs into `acc`.  LDS row = output row + r,
+// LDS column = output column + s (the 3x3 taps are r-1, s-1 of the 5x5 window).  The LDS reads of
+// the first steps are issued, then `between()` runs (it may still read the previous contents of
+// `acc`), then the accumulators are set to the biases and the MFMA steps run.
+template <bool EXACT, int ROWS, typename F>
+__device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *buf, int R0, int cb, int c, int g, const v4i *w22,
+                                        const v4i *w21, const C2Consts &k, F &&between)
+{
+    using namespace ka;
+    using PO = C2PlanOf<ROWS>;  // PO::P is the plan
+    constexpr int IN = C2Plan<ROWS>::IN, STEPS = C2Plan<ROWS>::STEPS;
+    const unsigned char *rowbase = buf + (R0 * C1C + cb + c) * 64;
+    const unsigned char *colbase[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
+    v4i item[C2Plan<ROWS>::ITEMS];
+    auto issue = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if constexpr (PO::P.kind[J] == 0)
+            item[J] = *reinterpret_cast<const v4i *>(colbase[PO::P.a0[J]] + PO::P.a1[J] * (C1C * 64));
+        else if constexpr (PO::P.kind[J] == 1)
+            item[J] = w22[(PO::P.a0[J] * 5 + PO::P.a1[J]) * 64];
+        else
+            item[J] = w21[((PO::P.a0[J] * 3 + PO::P.a1[J]) * 2 + PO::P.a2[J]) * 64];
+    };
+    static_range<0, c2_issued<ROWS>(-1)>(issue);
+    __builtin_amdgcn_sched_barrier(0);
+    between();
+    __builtin_amdgcn_sched_barrier(0);
+    C2_STAMP();
+#pragma unroll
+    for (int y = 0; y < ROWS; ++y) {
+        acc.a21[0][y] = k.b0;
+        acc.a21[1][y] = k.b1;
+        acc.a22[y] = k.b2;
+    }
+    static_for<STEPS>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int s = I / IN, yy = I % IN;
+        static_range<c2_issued<ROWS>(I - 1), c2_issued<ROWS>(I)>(issue);
+        const v4i B = item[PO::P.iB[s][yy]];
+        static_for<5>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int y = yy - r;
+            if constexpr (y >= 0 && y < ROWS) {
+                acc.a22[y] = mfma16(item[PO::P.i22[s][r]], B, acc.a22[y]);
+                if constexpr (s >= 1 && s <= 3 && r >= 1 && r <= 3) {
+                    acc.a21[0][y] = mfma16(item[PO::P.i21[s - 1][r - 1][0]], B, acc.a21[0][y]);
+                    acc.a21[1][y] = mfma16(item[PO::P.i21[s - 1][r - 1][1]], B, acc.a21[1][y]);
+                }
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (yy == IN - 1) C2_STAMP();
+    });
+}
+
 // Rows of a consumer's 8 x 16 block that the consumer itself computes; the PRODUCER wave on the same
 // SIMD would compute the rest after its C1 work.  Measured: with 7 the step does not get shorter (the
 // MFMA pipe and the vector issue port are shared by the two waves either way, and the producer's
 // one-row share reuses no fragment), so the consumer keeps all 8.
-constexpr int C2_CONS_ROWS = 8;
+#ifndef C2_CONS_ROWS_N
+#define C2_CONS_ROWS_N 8
+#endif
+constexpr int C2_CONS_ROWS = C2_CONS_ROWS_N;
 
 // End of a pipeline step: every LDS write of this wave has landed, then the workgroup barrier.
 // (A raw s_barrier: global loads and stores in flight are deliberately not waited for.)
@@ -233,6 +277,9 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
     const v4i *w22 = reinterpret_cast<const v4i *>(sW) + lane;
     const v4i *w21 = reinterpret_cast<const v4i *>(sW + (PackedOffsets::C2W21 - PackedOffsets::C2W22)) + lane;
     C2Consts kc;
+#ifdef QCNN_STAMPS
+    kc.dbg = a.dbg, kc.dbg_block = a.dbg_block, kc.row = wv, kc.idx = &stamp_idx;
+#endif
     kc.q21 = a.rq[1], kc.q22 = a.rq[2];
     kc.b0 = kc.b1 = kc.b2 = v4i{0, 0, 0, 0};
     if constexpr (!EXACT) {
@@ -381,14 +428,8 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                     auto c1_store = [&](int k, const v16i &d0, const v16i &d1) {
                         v4i o0, o1;
                         if constexpr (!EXACT) {
-                            o0.x = quant4<false>(d0[0], d0[1], d0[2], d0[3], 0.f, 0.f, 0.f, 0.f, q);
-                            o0.y = quant4<false>(d0[4], d0[5], d0[6], d0[7], 0.f, 0.f, 0.f, 0.f, q);
-                            o0.z = quant4<false>(d0[8], d0[9], d0[10], d0[11], 0.f, 0.f, 0.f, 0.f, q);
-                            o0.w = quant4<false>(d0[12], d0[13], d0[14], d0[15], 0.f, 0.f, 0.f, 0.f, q);
-                            o1.x = quant4<false>(d1[0], d1[1], d1[2], d1[3], 0.f, 0.f, 0.f, 0.f, q);
-                            o1.y = quant4<false>(d1[4], d1[5], d1[6], d1[7], 0.f, 0.f, 0.f, 0.f, q);
-                            o1.z = quant4<false>(d1[8], d1[9], d1[10], d1[11], 0.f, 0.f, 0.f, 0.f, q);
-                            o1.w = quant4<false>(d1[12], d1[13], d1[14], d1[15], 0.f, 0.f, 0.f, 0.f, q);
+                            o0 = requant16_int(d0, q);
+                            o1 = requant16_int(d1, q);
                         } else {
                             o0.x = quant4<true>(d0[0], d0[1], d0[2], d0[3], bf0[0], bf0[1], bf0[2], bf0[3], q);
                             o0.y = quant4<true>(d0[4], d0[5], d0[6], d0[7], bf0[4], bf0[5], bf0[6], bf0[7], q);
@@ -444,9 +485,13 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
             STAMP();
             // this wave's share of the C2 stage of tile n-1: the last rows of its consumer's block
             if constexpr (C2_CONS_ROWS < 8) {
-                if (n >= 1)
-                    c2_rows<EXACT, 8 - C2_CONS_ROWS>(smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
-                                                     a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
+                if (n >= 1) {
+                    C2Acc<8 - C2_CONS_ROWS> acc;
+                    c2_mfma<EXACT, 8 - C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
+                                                     [] {});
+                    c2_store<EXACT, 8 - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
+                                                      a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
+                }
             }
             if (n < N) {
                 prev = pos;
@@ -459,16 +504,28 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
     } else {
         // =============================== consumer ===============================
         // the first C2_CONS_ROWS rows of the SIMD's 8 x 16 block of tile n-1
+        // In step n the wave issues the first LDS reads of tile n-1, requantises and stores tile n-2
+        // (whose accumulators it still holds) while they travel, then runs the MFMAs of tile n-1.
+        C2Acc<C2_CONS_ROWS> acc;
+        TilePos held = pos;  // the tile whose results `acc` holds
+        bool have = false;
+        auto store_held = [&] {
+            if (have)
+                c2_store<EXACT, C2_CONS_ROWS>(acc, R0, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
+                                              held.ty * TH, H, W);
+        };
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n >= 1) {
-                c2_rows<EXACT, C2_CONS_ROWS>(smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc,
-                                             a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW, pos.ty * TH, H, W);
+                c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_held);
+                held = pos;
+                have = true;
                 advance(pos);
             }
             STAMP();
             step_barrier();
         }
+        store_held();
     }
 }
 

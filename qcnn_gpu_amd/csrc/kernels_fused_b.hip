@@ -297,11 +297,15 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
                 const int gx = x0 - 1 + jj, gy0 = y0 - 1 + R0;
                 unsigned char *dstbase = sC3 + (R0 * C3C + jj) * PX + 12 * g;
                 auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
-                    d0 = quant4<EXACT>(acc31[y][0], acc31[y][1], acc31[y][2], acc31[y][3], bf[0], bf[1], bf[2], bf[3], q31);
-                    d1 = quant4<EXACT>(acc32[0][y][0], acc32[0][y][1], acc32[0][y][2], acc32[0][y][3], bf[4], bf[5], bf[6], bf[7],
-                                       q32);
-                    d2 = quant4<EXACT>(acc32[1][y][0], acc32[1][y][1], acc32[1][y][2], acc32[1][y][3], bf[8], bf[9], bf[10],
-                                       bf[11], q32);
+                    if constexpr (!EXACT) {
+                        requant12_int(acc32[0][y], acc32[1][y], acc31[y], q32, q31, d1, d2, d0);
+                    } else {
+                        d0 = quant4<EXACT>(acc31[y][0], acc31[y][1], acc31[y][2], acc31[y][3], bf[0], bf[1], bf[2], bf[3], q31);
+                        d1 = quant4<EXACT>(acc32[0][y][0], acc32[0][y][1], acc32[0][y][2], acc32[0][y][3], bf[4], bf[5], bf[6], bf[7],
+                                           q32);
+                        d2 = quant4<EXACT>(acc32[1][y][0], acc32[1][y][1], acc32[1][y][2], acc32[1][y][3], bf[8], bf[9], bf[10],
+                                           bf[11], q32);
+                    }
                 };
                 if (gy0 >= 0 && gy0 + C3_WROWS <= H && x0 - 1 + cb >= 0 && x0 - 1 + cb + 16 <= W) {
                     // the wave's region pixels are all inside the frame

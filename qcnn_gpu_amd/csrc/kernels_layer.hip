@@ -14,11 +14,9 @@ Requant make_requant(int blu, int mul, int shift)
     r.bias = (mul != 0 && shift >= 1) ? (int)((1u << (shift - 1)) / (unsigned)mul) : 0;
     r.cmul = (int)((unsigned)r.bias * (unsigned)mul);
     r.bluf = (float)blu;
-    const int target = shift <= 16 ? 16 : 24;
-    const int k = target - shift;
-    r.mulk = (int)((unsigned)mul << k);
-    r.cmulk = (int)((unsigned)r.cmul << k);
-    r.sel2 = target == 16 ? 0x0c0c0602u : 0x0c0c0703u;
+    const int k = 24 - shift;
+    r.mulk = k >= 0 ? (int)((unsigned)mul << k) : 0;
+    r.cmulk = k >= 0 ? (int)((unsigned)r.cmul << k) : 0;
     return r;
 }
 

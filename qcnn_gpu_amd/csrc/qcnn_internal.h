@@ -17,11 +17,9 @@ struct Requant {
     int bias;   // (1 << (shift-1)) / mul
     int cmul;   // bias * mul  (so that (v + bias) * mul == v * mul + cmul, mod 2^32)
     float bluf; // (float)blu, the value the reference's float compare sees
-    // integer fast path: mul and cmul shifted left by k so that shift + k is 16 or 24; the
-    // quotient is then byte 2 or 3 of the product and sel2 is the v_perm selector that gathers
-    // that byte of two products into the low half of a dword.
+    // integer fast path: mul and cmul shifted left by 24 - shift, so that the quotient is byte 3 of
+    // the 32-bit value s * mulk + cmulk (0 when shift > 24: the fast path is then not used)
     int mulk, cmulk;
-    unsigned sel2;
 };
 
 // ---- fused kernel geometry -------------------------------------------------------------

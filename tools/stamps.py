@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from qcnn_gpu_amd import capi, synth  # noqa: E402
 
-capi.LIB_PATH = os.path.join(ROOT, "qcnn_gpu_amd", "lib_stamps", "libqcnn.so")
+capi.LIB_PATH = os.path.join(ROOT, "qcnn_gpu_amd", os.environ.get("STAMPS_LIB", "lib_stamps"), "libqcnn.so")
 from qcnn_gpu_amd.qvrcnn import qvrcnn  # noqa: E402
 
 h, w, qp = 1080, 1920, 37

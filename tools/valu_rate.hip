@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O2 tools/valu_rate.hip -o tools/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -82,17 +83,17 @@ __global__ __launch_bounds__(512) void k(long long *out, int *sink, int mode, in
 }
 
 template <int OP>
-static void run(const char *name)
+static void run(const char *name, int grid)
 {
     long long *out;
     int *sink;
-    hipMalloc(&out, 8 * 8 * sizeof(long long));
+    hipMalloc(&out, (size_t)grid * 8 * sizeof(long long));
     hipMalloc(&sink, 512 * sizeof(int));
     const int iters = 64;  // 64 * 64 = 4096 VALU instructions per wave
     for (int mode = 0; mode < 3; ++mode) {
-        hipMemset(out, 0, 64 * sizeof(long long));
-        k<OP><<<1, 512>>>(out, sink, mode, iters);
-        k<OP><<<1, 512>>>(out, sink, mode, iters);
+        hipMemset(out, 0, (size_t)grid * 8 * sizeof(long long));
+        k<OP><<<grid, 512>>>(out, sink, mode, iters);
+        k<OP><<<grid, 512>>>(out, sink, mode, iters);
         hipDeviceSynchronize();
         long long h[8];
         hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
@@ -105,15 +106,17 @@ static void run(const char *name)
     hipFree(sink);
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    run<3>("v_add_u32");
-    run<0>("v_mad_u32_u24");
-    run<7>("v_mad_i32_i24");
-    run<1>("v_perm_b32");
-    run<2>("v_med3_i32");
-    run<4>("v_max/min_i32");
-    run<6>("v_ashrrev_i32");
-    run<5>("v_mul_lo_u32");
+    const int grid = argc > 1 ? atoi(argv[1]) : 1;
+    printf("grid %d workgroups of 512 threads\n", grid);
+    run<3>("v_add_u32", grid);
+    run<0>("v_mad_u32_u24", grid);
+    run<7>("v_mad_i32_i24", grid);
+    run<1>("v_perm_b32", grid);
+    run<2>("v_med3_i32", grid);
+    run<4>("v_max/min_i32", grid);
+    run<6>("v_ashrrev_i32", grid);
+    run<5>("v_mul_lo_u32", grid);
     return 0;
 }
