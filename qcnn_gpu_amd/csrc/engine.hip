@@ -181,13 +181,16 @@ static void pack_fragments(const LayerView L[6], std::vector<int8_t> &out)
 }
 
 // Decides whether the integer fast path reproduces the reference's float32 pipeline for THIS
-// model.  With every |acc|, |bias| and |acc + bias| below 2^23 all float operations are exact and
-// s = acc + bias is a signed 24-bit operand of the requantiser's multiply; with
-// requant(blu) == 127 the clip-to-127 arm equals requantising min(s, blu), and the saturating
-// 32-bit form s * mulk + cmulk (see requant4_int) keeps byte 3 at 127 beyond it.
+// model.  With every |acc|, |bias| and |acc + bias| (+ the requantiser's rounding offset, which the
+// integer path adds to the bias) below 2^23 all float operations are exact and the sum is a signed
+// 24-bit operand of the requantiser's multiply; with requant(blu) == 127 the clip-to-127 arm
+// equals requantising min(u, blu), and the saturating 32-bit product (see requant4_int) keeps
+// byte 3 at 127 beyond it.
 static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
 {
     for (int l = 0; l < 5; ++l) {
+        const Requant &q = rq[l];
+        if (q.blu < 0 || q.mul <= 0 || q.shift > 24 || q.bias < 0) return false;
         const int in_max = l == 0 ? 128 : 127;  // C1 input is x-128 in [-128,127]; others are in [0,127]
         for (int k = 0; k < L[l].cout; ++k) {
             long long sum = 0;
@@ -195,14 +198,12 @@ static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
                 for (int r = 0; r < L[l].ks; ++r)
                     for (int s = 0; s < L[l].ks; ++s) sum += std::abs(L[l].at(k, c, r, s));
             const long long b = std::llabs((long long)L[l].b[k]);
-            if (sum * in_max + b >= (1ll << 23)) return false;
+            if (sum * in_max + b + q.bias >= (1ll << 23)) return false;
         }
-        const Requant &q = rq[l];
-        if (q.blu < 0 || q.mul <= 0 || q.shift > 24) return false;
         if ((long long)q.blu + q.bias >= (1ll << 23)) return false;
         const long long top = ((long long)(q.blu + q.bias) * q.mul) >> q.shift;
         if (top != 127) return false;  // also bounds (blu + bias) * mulk below 128 << 24 = 2^31
-        // pre-shifted multiplier: a positive signed 24-bit operand; cmulk = bias * mul << k <= 2^23
+        // pre-shifted multiplier: a positive signed 24-bit operand; bias * mulk <= 2^23
         if (((long long)q.mul << (24 - q.shift)) >= (1ll << 23)) return false;
     }
     return true;
@@ -240,7 +241,14 @@ static int load_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
     // make sure no kernel of a previous forward pass still reads the old parameters
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->wpack, packed.data(), packed.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->bias_i, bias_i.data(), 161 * sizeof(int), hipMemcpyHostToDevice));
+    {
+        // the integer path starts its accumulators from bias + rounding offset of the requantiser
+        std::vector<int32_t> start(bias_i);
+        if (!e->exact)
+            for (int l = 0; l < 5; ++l)
+                for (int k = 0; k < L_COUT[l]; ++k) start[BIAS_OFF[l] + k] += e->rq[l].bias;
+        HIP_TRY(hipMemcpy(e->bias_i, start.data(), 161 * sizeof(int), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(e->bias_f, bias_f.data(), 161 * sizeof(float), hipMemcpyHostToDevice));
     for (int l = 0; l < 6; ++l) HIP_TRY(hipMemcpy(e->w_file[l], L[l].w, wsize(l), hipMemcpyHostToDevice));
     e->loaded = true;

@@ -48,13 +48,13 @@ __device__ __forceinline__ int requant_float(int acc, float bf, const Requant &q
 }
 
 // Integer requantiser of four consecutive channels, valid when the host-side proof holds (see
-// engine.hip, prove_integer_path).  s = acc + bias is exactly what the reference's float u holds
-// and fits 24 signed bits; mul and bias * mul are pre-shifted on the host by 24 - shift, so the
-// quotient ((s + bias) * mul) >> shift is byte 3 of t = s * mulk + cmulk.  Two instructions per
-// channel:
-//   t = saturate_i32(s * mulk + cmulk)       v_mad_i32_i24 ... clamp
-//       s > blu : t >= requant(blu) << 24 = 127 << 24, and saturation keeps byte 3 at 127;
-//       s < 0   : t < 2^23, so byte 3 is 0 or negative
+// engine.hip, prove_integer_path).  s = acc + bias + q.bias: what the reference's float u holds plus
+// the requantiser's rounding offset, which the host folds into the bias the accumulators start
+// from; it fits 24 signed bits.  mul is pre-shifted on the host by 24 - shift, so the quotient
+// (s * mul) >> shift is byte 3 of t = s * mulk.  Two instructions per channel:
+//   t = saturate_i32(s * mulk)               v_mad_i32_i24 t, s, mulk, 0 clamp  (one VGPR operand)
+//       u > blu : t >= requant(blu) << 24 = 127 << 24, and saturation keeps byte 3 at 127;
+//       u < 0   : t < q.bias * mulk <= 2^23, so byte 3 is 0 or negative
 //   byte j of the dword = max(sext(t[31:24]), 0)   v_max_i32 with sub-dword source and destination
 // which is both clip arms of the reference and its store-to-char truncation.  A sub-dword write
 // must not be followed directly by a vector instruction that reads the register (one wait state):
@@ -63,17 +63,17 @@ __device__ __forceinline__ unsigned requant4_int(int s0, int s1, int s2, int s3,
 {
     unsigned p;
     int t;
-    asm("v_mad_i32_i24 %1, %2, %6, %7 clamp\n\t"
+    asm("v_mad_i32_i24 %1, %2, %6, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %1, %3, %6, %7 clamp\n\t"
+        "v_mad_i32_i24 %1, %3, %6, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %1, %4, %6, %7 clamp\n\t"
+        "v_mad_i32_i24 %1, %4, %6, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %1, %5, %6, %7 clamp\n\t"
+        "v_mad_i32_i24 %1, %5, %6, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "s_nop 0"
         : "=&v"(p), "=&v"(t)
-        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(q.mulk), "v"(q.cmulk));
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "s"(q.mulk));
     return p;
 }
 
@@ -84,34 +84,34 @@ __device__ __forceinline__ void requant12_int(const v4i &a, const v4i &b, const 
                                               unsigned &pa, unsigned &pb, unsigned &pc)
 {
     int ta, tb, tc;
-    asm("v_mad_i32_i24 %3, %6, %18, %19 clamp\n\t"
-        "v_mad_i32_i24 %4, %10, %20, %21 clamp\n\t"
-        "v_mad_i32_i24 %5, %14, %22, %23 clamp\n\t"
+    asm("v_mad_i32_i24 %3, %6, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %4, %10, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %14, %19, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %3, %7, %18, %19 clamp\n\t"
-        "v_mad_i32_i24 %4, %11, %20, %21 clamp\n\t"
-        "v_mad_i32_i24 %5, %15, %22, %23 clamp\n\t"
+        "v_mad_i32_i24 %3, %7, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %4, %11, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %15, %19, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %3, %8, %18, %19 clamp\n\t"
-        "v_mad_i32_i24 %4, %12, %20, %21 clamp\n\t"
-        "v_mad_i32_i24 %5, %16, %22, %23 clamp\n\t"
+        "v_mad_i32_i24 %3, %8, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %4, %12, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %16, %19, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %3, %9, %18, %19 clamp\n\t"
-        "v_mad_i32_i24 %4, %13, %20, %21 clamp\n\t"
-        "v_mad_i32_i24 %5, %17, %22, %23 clamp\n\t"
+        "v_mad_i32_i24 %3, %9, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %4, %13, %18, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %17, %19, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "s_nop 0"
         : "=&v"(pa), "=&v"(pb), "=&v"(pc), "=&v"(ta), "=&v"(tb), "=&v"(tc)
         : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
-          "v"(qab.mulk), "v"(qab.cmulk), "v"(qab.mulk), "v"(qab.cmulk), "v"(qc.mulk), "v"(qc.cmulk));
+          "s"(qab.mulk), "s"(qc.mulk));
 }
 
 // The same for the 16 channels of one 32x32 accumulator (four dwords, one requantiser).
@@ -119,34 +119,34 @@ __device__ __forceinline__ v4i requant16_int(const v16i &d, const Requant &q)
 {
     unsigned p0, p1, p2, p3;
     int t0, t1, t2, t3;
-    asm("v_mad_i32_i24 %4, %8, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %5, %12, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %6, %16, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %7, %20, %24, %25 clamp\n\t"
+    asm("v_mad_i32_i24 %4, %8, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %12, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %6, %16, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %7, %20, %24, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %3, sext(%7), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %4, %9, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %5, %13, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %6, %17, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %7, %21, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %4, %9, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %13, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %6, %17, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %7, %21, %24, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %3, sext(%7), 0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %4, %10, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %5, %14, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %6, %18, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %7, %22, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %4, %10, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %14, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %6, %18, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %7, %22, %24, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %3, sext(%7), 0 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_mad_i32_i24 %4, %11, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %5, %15, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %6, %19, %24, %25 clamp\n\t"
-        "v_mad_i32_i24 %7, %23, %24, %25 clamp\n\t"
+        "v_mad_i32_i24 %4, %11, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %5, %15, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %6, %19, %24, 0 clamp\n\t"
+        "v_mad_i32_i24 %7, %23, %24, 0 clamp\n\t"
         "v_max_i32_sdwa %0, sext(%4), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %1, sext(%5), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
         "v_max_i32_sdwa %2, sext(%6), 0 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"
@@ -154,7 +154,7 @@ __device__ __forceinline__ v4i requant16_int(const v16i &d, const Requant &q)
         "s_nop 0"
         : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
         : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]), "v"(d[9]), "v"(d[10]),
-          "v"(d[11]), "v"(d[12]), "v"(d[13]), "v"(d[14]), "v"(d[15]), "v"(q.mulk), "v"(q.cmulk));
+          "v"(d[11]), "v"(d[12]), "v"(d[13]), "v"(d[14]), "v"(d[15]), "s"(q.mulk));
     return v4i{(int)p0, (int)p1, (int)p2, (int)p3};
 }
 

@@ -16,7 +16,6 @@ Requant make_requant(int blu, int mul, int shift)
     r.bluf = (float)blu;
     const int k = 24 - shift;
     r.mulk = k >= 0 ? (int)((unsigned)mul << k) : 0;
-    r.cmulk = k >= 0 ? (int)((unsigned)r.cmul << k) : 0;
     return r;
 }
 

@@ -17,9 +17,9 @@ struct Requant {
     int bias;   // (1 << (shift-1)) / mul
     int cmul;   // bias * mul  (so that (v + bias) * mul == v * mul + cmul, mod 2^32)
     float bluf; // (float)blu, the value the reference's float compare sees
-    // integer fast path: mul and cmul shifted left by 24 - shift, so that the quotient is byte 3 of
-    // the 32-bit value s * mulk + cmulk (0 when shift > 24: the fast path is then not used)
-    int mulk, cmulk;
+    // integer fast path: mul shifted left by 24 - shift, so that the quotient is byte 3 of the 32-bit
+    // value (v + bias) * mulk (0 when shift > 24: the fast path is then not used)
+    int mulk;
 };
 
 // ---- fused kernel geometry -------------------------------------------------------------
@@ -75,7 +75,9 @@ struct FusedArgs {
     size_t frame_stride;     // bytes between consecutive frames of y and of rec
     size_t conc_stride;      // bytes between consecutive frames of conc1
     const int8_t *wpack;     // packed fragments, PackedOffsets
-    const int *bias_i;       // int32 biases, 6 layers concatenated: 64,32,16,16,32,1 (=161)
+    const int *bias_i;       // int32 biases, 6 layers concatenated: 64,32,16,16,32,1 (=161); layers 0..4 with the
+                             // requantiser's rounding offset (Requant::bias) added: the integer path starts its
+                             // accumulators from them
     const float *bias_f;     // same, converted to float as CovLayer::load_static_para does
     int H, W;
     int ncu;                 // compute units of the device (grid size of the persistent kernel)
