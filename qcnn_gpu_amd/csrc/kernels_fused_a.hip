@@ -222,6 +222,12 @@ __device__ __forceinline__ void step_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// Barrier inside a step: the producers wait here until the consumers have stored their previous
+// tile, so that the two vector-heavy phases of a SIMD's wave pair do not run side by side.
+__device__ __forceinline__ void mid_barrier()
+{
+    asm volatile("s_barrier" ::: "memory");
+}
 
 template <bool EXACT>
 __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
@@ -353,27 +359,44 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         constexpr int YLOADS = (9 * YWC + 63) / 64;  // bytes of the private Y tile per lane
         // byte `it` of this lane: offset in the frame relative to the tile's first halo pixel, LDS
         // offset in copy 0 (copy c sits c * (YCOPY - 1) further; -1: no byte), row | column << 8
-        int yoff[YLOADS], ywr[YLOADS], yrc[YLOADS];
+        int ywr[YLOADS], yrc[YLOADS];
 #pragma unroll
         for (int it = 0; it < YLOADS; ++it) {
             const int idx = it * 64 + lane;
             const int row = idx / YWC, col = idx - row * YWC;
-            yoff[it] = row * W + col;
             ywr[it] = idx < 9 * YWC ? row * YWS + col + 4 : -1;
             yrc[it] = row | (col << 8);
         }
+        // The same tile as dwords, for tiles whose halo (and 3 bytes beyond it) lies inside the frame:
+        // dword i of row `row` of copy c holds columns 4i+c .. 4i+c+3, which is one unaligned dword of
+        // the frame, so a lane moves 4 bytes per load and per conflict-free ds_write_b32 instead of 1
+        // (columns >= YWC only meet zero weights).  goff4: offset in the frame; lwr4: LDS offset, -1: none.
+        static_assert(YWC % 4 == 0 && YCOPY % 4 == 0, "the Y tile is a whole number of aligned dwords per row");
+        constexpr int YDW = YWC / 4, YDWORDS = 4 * 9 * YDW, YLOADS4 = (YDWORDS + 63) / 64;
+        int goff4[YLOADS4], lwr4[YLOADS4];
+#pragma unroll
+        for (int it = 0; it < YLOADS4; ++it) {
+            const int q = it * 64 + lane;
+            const int cc = q / (9 * YDW), rem = q - cc * (9 * YDW);
+            const int row = rem / YDW, i = rem - row * YDW;
+            goff4[it] = row * W + 4 * i + cc;
+            lwr4[it] = q < YDWORDS ? cc * YCOPY + row * YWS + 4 + 4 * i : -1;
+        }
         unsigned char ypre[YLOADS];
+        unsigned ypre4[YLOADS4];
+        bool pre_dwords = false;  // which of the two staging sets the last fetch_y filled
         auto fetch_y = [&](const TilePos &tp, bool warm) {
             // first halo pixel of this producer's rows
             const int xa = tp.tx * TW - 4, ya = tp.ty * TH - 4 + (warm ? 4 + WARM_ROWS * p : PROD_ROWS * p);
             const uint8_t *yf = a.y + (size_t)tp.f * a.frame_stride;
-            if (xa >= 0 && xa + YWC <= W && ya >= 0 && ya + 9 <= H) {  // inside the frame
+            pre_dwords = xa >= 0 && xa + YWC + 3 <= W && ya >= 0 && ya + 9 <= H;
+            if (pre_dwords) {  // inside the frame: raw bytes, turned into x - 128 when they are written to LDS
                 const uint8_t *org = yf + (size_t)ya * W + xa;
 #pragma unroll
-                for (int it = 0; it < YLOADS; ++it) {
-                    unsigned char v = 0;
-                    if (it + 1 < YLOADS || ywr[it] >= 0) v = org[yoff[it]];
-                    ypre[it] = v ^ 0x80;
+                for (int it = 0; it < YLOADS4; ++it) {
+                    unsigned v = 0;
+                    if (it + 1 < YLOADS4 || lwr4[it] >= 0) __builtin_memcpy(&v, org + goff4[it], 4);
+                    ypre4[it] = v;
                 }
             } else {  // frame edge: clamped addresses; I1.ppro of the zero padding is (x - 128) == 0
 #pragma unroll
@@ -390,15 +413,22 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         advance(nxt);
         for (int n = 0; n <= N; ++n) {
             STAMP();
+            mid_barrier();
             if (n < N) {
                 const int x0 = pos.tx * TW, y0 = pos.ty * TH;
                 const bool warm = n > 0 && pos.ty > 0;  // the tile above was this workgroup's previous tile
                 unsigned char *buf = smem + (n & 1) * SC1_BYTES;
+                if (pre_dwords) {
 #pragma unroll
-                for (int it = 0; it < YLOADS; ++it) {
-                    if (ywr[it] >= 0) {
+                    for (int it = 0; it < YLOADS4; ++it)
+                        if (lwr4[it] >= 0) *reinterpret_cast<unsigned *>(sYw + lwr4[it]) = ypre4[it] ^ 0x80808080u;
+                } else {
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) sYw[ywr[it] + cc * (YCOPY - 1)] = ypre[it];
+                    for (int it = 0; it < YLOADS; ++it) {
+                        if (ywr[it] >= 0) {
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) sYw[ywr[it] + cc * (YCOPY - 1)] = ypre[it];
+                        }
                     }
                 }
                 if (n + 1 < N) fetch_y(nxt, nxt.ty > 0);  // next tile's bytes travel while this one is computed
@@ -514,13 +544,19 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 c2_store<EXACT, C2_CONS_ROWS>(acc, R0, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
                                               held.ty * TH, H, W);
         };
+        auto store_then_release = [&] {
+            store_held();
+            mid_barrier();
+        };
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n >= 1) {
-                c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_held);
+                c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_then_release);
                 held = pos;
                 have = true;
                 advance(pos);
+            } else {
+                mid_barrier();
             }
             STAMP();
             step_barrier();
