@@ -367,37 +367,28 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
             ywr[it] = idx < 9 * YWC ? row * YWS + col + 4 : -1;
             yrc[it] = row | (col << 8);
         }
-        // The same tile as dwords, for tiles whose halo (and 3 bytes beyond it) lies inside the frame:
-        // dword i of row `row` of copy c holds columns 4i+c .. 4i+c+3, which is one unaligned dword of
-        // the frame, so a lane moves 4 bytes per load and per conflict-free ds_write_b32 instead of 1
-        // (columns >= YWC only meet zero weights).  goff4: offset in the frame; lwr4: LDS offset, -1: none.
-        static_assert(YWC % 4 == 0 && YCOPY % 4 == 0, "the Y tile is a whole number of aligned dwords per row");
-        constexpr int YDW = YWC / 4, YDWORDS = 4 * 9 * YDW, YLOADS4 = (YDWORDS + 63) / 64;
-        int goff4[YLOADS4], lwr4[YLOADS4];
-#pragma unroll
-        for (int it = 0; it < YLOADS4; ++it) {
-            const int q = it * 64 + lane;
-            const int cc = q / (9 * YDW), rem = q - cc * (9 * YDW);
-            const int row = rem / YDW, i = rem - row * YDW;
-            goff4[it] = row * W + 4 * i + cc;
-            lwr4[it] = q < YDWORDS ? cc * YCOPY + row * YWS + 4 + 4 * i : -1;
-        }
+        // The same tile in one load, for tiles whose halo (and 3 bytes beyond it) lies inside the frame:
+        // lane (row, j), j = 0..4, loads the 12 bytes 8j .. 8j+11 of tile row `row` and derives from them
+        // dwords 2j and 2j+1 of all four copies (dword i of copy c holds columns 4i+c .. 4i+c+3 = a byte
+        // alignment of two neighbouring dwords), so the wave issues one global load and eight
+        // conflict-free ds_write_b32 instead of a load and four byte stores per 64 bytes (columns >= YWC
+        // only meet zero weights).
+        static_assert(YWC == 40 && YCOPY % 4 == 0, "five 8-byte pieces per tile row");
+        const int yrow4 = lane / 5, yj4 = lane - yrow4 * 5;
+        const bool ylane4 = lane < 45;
+        const int goff4 = ylane4 ? yrow4 * W + 8 * yj4 : 0;
+        const int lwr4 = yrow4 * YWS + 4 + 8 * yj4;  // copy c sits c * YCOPY further
         unsigned char ypre[YLOADS];
-        unsigned ypre4[YLOADS4];
+        unsigned ypre4[3];
         bool pre_dwords = false;  // which of the two staging sets the last fetch_y filled
         auto fetch_y = [&](const TilePos &tp, bool warm) {
             // first halo pixel of this producer's rows
             const int xa = tp.tx * TW - 4, ya = tp.ty * TH - 4 + (warm ? 4 + WARM_ROWS * p : PROD_ROWS * p);
             const uint8_t *yf = a.y + (size_t)tp.f * a.frame_stride;
-            pre_dwords = xa >= 0 && xa + YWC + 3 <= W && ya >= 0 && ya + 9 <= H;
+            pre_dwords = xa >= 0 && xa + YWC + 4 <= W && ya >= 0 && ya + 9 <= H;
             if (pre_dwords) {  // inside the frame: raw bytes, turned into x - 128 when they are written to LDS
                 const uint8_t *org = yf + (size_t)ya * W + xa;
-#pragma unroll
-                for (int it = 0; it < YLOADS4; ++it) {
-                    unsigned v = 0;
-                    if (it + 1 < YLOADS4 || lwr4[it] >= 0) __builtin_memcpy(&v, org + goff4[it], 4);
-                    ypre4[it] = v;
-                }
+                if (ylane4) __builtin_memcpy(ypre4, org + goff4, 12);
             } else {  // frame edge: clamped addresses; I1.ppro of the zero padding is (x - 128) == 0
 #pragma unroll
                 for (int it = 0; it < YLOADS; ++it) {
@@ -419,9 +410,15 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 const bool warm = n > 0 && pos.ty > 0;  // the tile above was this workgroup's previous tile
                 unsigned char *buf = smem + (n & 1) * SC1_BYTES;
                 if (pre_dwords) {
+                    if (ylane4) {
+                        const unsigned d0 = ypre4[0] ^ 0x80808080u, d1 = ypre4[1] ^ 0x80808080u, d2 = ypre4[2] ^ 0x80808080u;
 #pragma unroll
-                    for (int it = 0; it < YLOADS4; ++it)
-                        if (lwr4[it] >= 0) *reinterpret_cast<unsigned *>(sYw + lwr4[it]) = ypre4[it] ^ 0x80808080u;
+                        for (int cc = 0; cc < 4; ++cc) {
+                            unsigned *dst = reinterpret_cast<unsigned *>(sYw + cc * YCOPY + lwr4);
+                            dst[0] = cc ? __builtin_amdgcn_alignbyte(d1, d0, cc) : d0;
+                            dst[1] = cc ? __builtin_amdgcn_alignbyte(d2, d1, cc) : d1;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int it = 0; it < YLOADS; ++it) {
@@ -507,10 +504,9 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                         const int i = i0 + p * 64 + lane;
                         if (i < PIECES) dst[i] = src[i];
                     }
-                    produce(std::integral_constant<int, 1>{});
-                } else {
-                    produce(std::integral_constant<int, 0>{});
                 }
+                if (warm) produce(std::integral_constant<int, 1>{});
+                else produce(std::integral_constant<int, 0>{});
             }
             STAMP();
             // this wave's share of the C2 stage of tile n-1: the last rows of its consumer's block
@@ -551,9 +547,16 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         for (int n = 0; n <= N; ++n) {
             STAMP();
             if (n >= 1) {
-                c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_then_release);
-                held = pos;
-                have = true;
+                if constexpr (EXACT) {
+                    // the float pipeline needs its registers for the requant: results are stored at once
+                    c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
+                    c2_store<EXACT, C2_CONS_ROWS>(acc, R0, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
+                                                  pos.ty * TH, H, W);
+                } else {
+                    c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_then_release);
+                    held = pos;
+                    have = true;
+                }
                 advance(pos);
             } else {
                 mid_barrier();
