@@ -118,21 +118,20 @@ struct LayerView {
 static void pack_fragments(const LayerView L[6], std::vector<int8_t> &out)
 {
     out.assign(PackedOffsets::TOTAL, 0);
-    // C1: 32x32x32, fragment (t, m): 32-channel tile t, row group m.  Row rho of tile t is channel
+    // C1: 32x32x32, one fragment per 32-channel tile t.  Row rho of tile t is channel
     // 32t + chperm(rho), chosen so that lane (pixel, h) of the accumulator holds channels 16h..16h+15
-    // in registers 0..15.  K = 2 kernel rows x 8 columns per k-group: byte j of k-group h is kernel
-    // row 4m + 2h + (j >> 3), column j & 7; rows >= 5 and columns >= 5 are zero.
+    // in registers 0..15.  K = the 25 taps of the window, three kernel rows per k-group: byte j < 15 of
+    // k-group h is kernel row 3h + j / 5, column j % 5; byte 15 and kernel rows >= 5 are zero.
     for (int t = 0; t < 2; ++t)
-        for (int m = 0; m < 2; ++m)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int rho = lane & 31, h = lane >> 5;
-                const int ch = 32 * t + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
-                int8_t *dst = &out[PackedOffsets::C1W + ((t * 2 + m) * 64 + lane) * 16];
-                for (int j = 0; j < 16; ++j) {
-                    const int row = 4 * m + 2 * h + (j >> 3), col = j & 7;
-                    dst[j] = (row < 5 && col < 5) ? (int8_t)L[0].at(ch, 0, row, col) : 0;
-                }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int rho = lane & 31, h = lane >> 5;
+            const int ch = 32 * t + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+            int8_t *dst = &out[PackedOffsets::C1W + (t * 64 + lane) * 16];
+            for (int j = 0; j < 16; ++j) {
+                const int row = 3 * h + j / 5, col = j % 5;
+                dst[j] = (j < 15 && row < 5) ? (int8_t)L[0].at(ch, 0, row, col) : 0;
             }
+        }
     // C2_2 (5x5, 64 -> 16): fragment (s, r); row = channel; k-group g byte j = input channel 16g+j.
     for (int s = 0; s < 5; ++s)
         for (int r = 0; r < 5; ++r)

@@ -311,13 +311,14 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         //
         // The private image holds FOUR copies of the Y tile, copy c shifted left by c bytes, so the
         // 8 bytes Y[row][j .. j+7] of any column j are two aligned dwords of copy j&3: the im2col
-        // B fragment of a pixel is read straight from LDS.  C1 is then two chained 32x32x32 MFMAs
-        // per 32-channel tile: K = (kernel row pair, 8 columns), weights zero for columns 5..7 and
-        // rows >= 5, so whatever the padding bytes hold is multiplied by zero.
+        // B fragment of a pixel is read straight from LDS.  C1 is then one 32x32x32 MFMA per
+        // 32-channel tile: k-group h holds kernel rows 3h .. 3h+2, five bytes of each packed into 15
+        // K positions with four byte permutes; the 16th position and kernel rows >= 5 have zero
+        // weights, so whatever those bytes hold is multiplied by zero.
         const int p = wv;
         unsigned char *sYw = sYall + p * SYW_BYTES;  // [4][YWR][YWS] int8 (x - 128), 0 outside the frame
         const v4i *wp = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C1W) + lane;
-        const v4i A00 = wp[0], A01 = wp[64], A10 = wp[128], A11 = wp[192];  // [channel tile][row group]
+        const v4i A0 = wp[0], A1 = wp[64];  // one fragment per 32-channel tile
         const int h = lane >> 5;
         const Requant q = a.rq[0];
         v16i bias0 = {}, bias1 = {};
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         }
         // per-lane constants of the pixel groups k, for a cold tile (mode 0: region rows 5p .. 5p+4,
         // 180 pixels, 6 groups) and for a warm tile (mode 1: rows 4+4p .. 7+4p, 144 pixels, 5 groups):
-        // LDS read address (k-group h = kernel rows 2h, 2h+1; rows 4, 5 sit 4 rows further), LDS
+        // LDS read address (k-group h = kernel rows 3h .. 3h+2), LDS
         // write address, region coordinates
         constexpr int NKC = (PROD_ROWS * C1C + 31) / 32, NKW = (WARM_ROWS * C1C + 31) / 32;
         int rd[2][NKC], wr[2][NKC], ij[2][NKC];
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 const int qc = qi < npix ? qi : npix - 1;
                 const int il = qc / C1C, j = qc - il * C1C;
                 const int cc = j & 3;
-                rd[mode][k] = cc * YCOPY + (il + 2 * h) * YWS + (j - cc) + 4;
+                rd[mode][k] = cc * YCOPY + (il + 3 * h) * YWS + (j - cc) + 4;
                 const int i = row0 + il;
                 wr[mode][k] = (i * C1C + j) * 64 + swz(h, j);
                 ij[mode][k] = i | (j << 8);
@@ -436,20 +437,19 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                     constexpr int NK = MODE ? NKW : NKC;
                     // C1 MFMAs of pixel group k: the B fragments come straight from the shifted copies
                     auto c1_mfma = [&](int k, v16i &d0, v16i &d1) {
+                        // rows 3h, 3h+1, 3h+2 of the window, 8 bytes each; the first 5 of each row are
+                        // packed into 15 consecutive K positions (the 16th has zero weight)
                         const unsigned *src = reinterpret_cast<const unsigned *>(sYw + rd[MODE][k]);
-                        v4i B1, B2;
-                        B1.x = (int)src[0];
-                        B1.y = (int)src[1];
-                        B1.z = (int)src[YWS / 4];
-                        B1.w = (int)src[YWS / 4 + 1];
-                        B2.x = (int)src[YWS];       // 4 rows further: kernel row 4 for k-group 0
-                        B2.y = (int)src[YWS + 1];
-                        B2.z = B2.x;                // kernel row 5: zero weights
-                        B2.w = B2.y;
-                        d0 = mfma32(A00, B1, bias0);
-                        d1 = mfma32(A10, B1, bias1);
-                        d0 = mfma32(A01, B2, d0);
-                        d1 = mfma32(A11, B2, d1);
+                        const unsigned r0l = src[0], r0h = src[1];
+                        const unsigned r1l = src[YWS / 4], r1h = src[YWS / 4 + 1];
+                        const unsigned r2l = src[YWS / 2], r2h = src[YWS / 2 + 1];
+                        v4i B;
+                        B.x = (int)r0l;
+                        B.y = (int)__builtin_amdgcn_perm(r1l, r0h, 0x06050400u);  // r0[4] r1[0] r1[1] r1[2]
+                        B.z = (int)__builtin_amdgcn_perm(r2l, __builtin_amdgcn_alignbyte(r1h, r1l, 3), 0x05040100u);  // r1[3] r1[4] r2[0] r2[1]
+                        B.w = (int)__builtin_amdgcn_alignbyte(r2h, r2l, 2);        // r2[2] r2[3] r2[4] (zero weight)
+                        d0 = mfma32(A0, B, bias0);
+                        d1 = mfma32(A1, B, bias1);
                     };
                     // requant + store of pixel group k
                     auto c1_store = [&](int k, const v16i &d0, const v16i &d1) {

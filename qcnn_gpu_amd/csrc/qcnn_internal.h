@@ -57,8 +57,8 @@ static_assert(LDS_BYTES <= 160 * 1024, "kernel B exceeds the 160 KiB of LDS of o
 // Offsets (bytes) of the packed MFMA A-operand fragments inside one device buffer.
 // One fragment = 64 lanes x 16 bytes = 1 KiB, stored in lane order.
 struct PackedOffsets {
-    static constexpr int C1W = 0;                       // 4 fragments (32x32x32) [channel tile][row group]
-    static constexpr int C2W22 = C1W + 4 * 1024;        // 25 fragments [s][r]
+    static constexpr int C1W = 0;                       // 2 fragments (32x32x32) [channel tile]
+    static constexpr int C2W22 = C1W + 2 * 1024;        // 25 fragments [s][r]
     static constexpr int C2W21 = C2W22 + 25 * 1024;     // 18 fragments [s'][r'][t]
     static constexpr int C3W31 = C2W21 + 18 * 1024;     // 9 fragments [s][r]
     static constexpr int C3W32 = C3W31 + 9 * 1024;      // 2 fragments [t]
