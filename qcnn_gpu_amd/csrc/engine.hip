@@ -205,6 +205,21 @@ static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
         // pre-shifted multiplier: a positive signed 24-bit operand; bias * mulk <= 2^23
         if (((long long)q.mul << (24 - q.shift)) >= (1ll << 23)) return false;
     }
+    // C4 + applyRes_y in integers: |acc + bias| and the multiplier are 24-bit operands, the product plus
+    // the rounding term stays below 2^31 (so the reference's unsigned arithmetic does not wrap), and
+    // pixel + residual fits the reference's short
+    {
+        const Requant &q = rq[5];
+        long long sum = 0;
+        for (int c = 0; c < L[5].cin; ++c)
+            for (int r = 0; r < L[5].ks; ++r)
+                for (int s = 0; s < L[5].ks; ++s) sum += std::abs(L[5].at(0, c, r, s));
+        const long long top = sum * 127 + std::llabs((long long)L[5].b[0]);
+        if (top >= (1ll << 23) || q.mul <= 0 || q.mul >= (1 << 23)) return false;
+        const long long prod = top * q.mul + (1ll << (q.shift - 1));
+        if (prod >= (1ll << 31)) return false;
+        if ((prod >> q.shift) + 255 >= 32767) return false;
+    }
     return true;
 }
 

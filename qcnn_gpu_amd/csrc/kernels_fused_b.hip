@@ -73,6 +73,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
         const v4i *w4 = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C4W) + lane;
         const v4i f4[3] = {w4[0], w4[64], w4[128]};
         const float b4 = a.bias_f[BIAS_OFF[5]];
+        const int b4i = EXACT ? 0 : a.bias_i[BIAS_OFF[5]];  // integer path (a zero accumulator start costs the MFMA nothing)
         const int mul = a.rq[5].mul, shift = a.rq[5].shift;
         constexpr int PIECES_ROW = INC * 3;  // 16-byte pieces per tile row
         constexpr int PIECES = INR * PIECES_ROW;
@@ -171,18 +172,33 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
                 });
                 STAMP();
                 if (g == 0 && ox < TW && gx < W) {
+                    uint8_t *dst = recf + (size_t)(y0 + O0) * W + gx;
+                    // all nine results first, each in a register of its own, then the stores: a store's data
+                    // register cannot be rewritten before the memory pipeline has read it
+                    uint8_t out[9];
 #pragma unroll
                     for (int y = 0; y < 9; ++y) {
-                        const int gy = y0 + O0 + y;
-                        if (gy < H) {
-                            const int acc = D[y][0] + D[y + 1][1] + D[y + 2][2];
+                        const int acc = D[y][0] + D[y + 1][1] + D[y + 2][2] + b4i;
+                        if constexpr (EXACT) {
                             const float u = (float)acc + b4;  // C4.u, inference/cnn.cu:148-155
                             int temp = (int)u;                // applyRes_GPU_y, inference/cnn.cu:515-520
                             temp = (int)((unsigned)temp * (unsigned)mul + (1u << (shift - 1))) >> shift;
                             const short rec = (short)((int)ypix[y] + temp);
-                            recf[(size_t)gy * W + gx] = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
+                            out[y] = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
+                        } else {
+                            // the same in integers: the host has proved that acc (bias included) and the
+                            // multiplier fit 24 bits, that the product does not wrap and that the sum with
+                            // the pixel fits a short
+                            const int temp = (__mul24(acc, mul) + (1 << (shift - 1))) >> shift;
+                            const int rec = (int)ypix[y] + temp;
+                            out[y] = (uint8_t)min(max(rec, 0), 255);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int nrows = H - (y0 + O0);
+#pragma unroll
+                    for (int y = 0; y < 9; ++y)
+                        if (y < nrows) dst[(size_t)y * W] = out[y];
                 }
             }
             STAMP();
