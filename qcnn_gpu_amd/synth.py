@@ -105,6 +105,9 @@ def adversarial_model(kind: str) -> StaticModel:
     """Edge-case models.
     'maxmag'   : every weight -128 / +127 so that |acc| crosses 2^24 in C2_2 (float-accumulator path).
     'identity' : C1 centre tap only, tiny ranges; accumulators sit exactly on 0 / blu / blu+1.
+    'wide'     : full-magnitude weights on as many taps as keep sum|w| * 127 + |b| just below 2^23, with
+                 the usual clip thresholds: accumulators run from far below zero to hundreds of times
+                 the threshold, which is what the integer requantiser's saturating multiply must survive.
     """
     m = synth_model(37)
     if kind == "maxmag":
@@ -116,6 +119,22 @@ def adversarial_model(kind: str) -> StaticModel:
             lp.b = np.full(lp.b.shape, (1 << 24) + 3 if l == 2 else 12345, np.int32)
             if l < 5:
                 lp.blu, lp.mul, lp.shift = (1 << 25), 1, 18
+        return m
+    if kind == "wide":
+        for l, lp in enumerate(m.layers):
+            co = lp.w.shape[0]
+            per = lp.w[0].size
+            in_max = 128 if l == 0 else 127
+            n = min(per, ((1 << 23) - 70000) // (127 * in_max))  # nonzero taps per output channel
+            w = np.zeros((co, per), np.int8)
+            for k in range(co):
+                idx = (np.arange(n) * 7 + k * 3) % per if per > n else np.arange(per)
+                sgn = np.where(((np.arange(idx.size) + k) * 2654435761 >> 9) & 1, 127, -127)
+                if k % 3 == 0:
+                    sgn[:] = 127   # all-positive channel: far above the threshold on bright input
+                w[k, idx] = sgn
+            lp.w = w.reshape(lp.w.shape)
+            lp.b = ((np.arange(co) % 7 - 3) * 9000).astype(np.int32)
         return m
     if kind == "identity":
         for l, lp in enumerate(m.layers):

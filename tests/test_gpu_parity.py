@@ -106,7 +106,7 @@ def test_fused_float_pipeline_variant(qp):
         _check_fused(net, y, rec_o, taps_o["conc1"])
 
 
-@pytest.mark.parametrize("kind", ["maxmag", "identity"])
+@pytest.mark.parametrize("kind", ["maxmag", "identity", "wide"])
 def test_adversarial_models(kind):
     m = synth.adversarial_model(kind)
     mb = m.to_nchw_vect_c_bytes()
@@ -115,6 +115,8 @@ def test_adversarial_models(kind):
         net.load_static_para(mb)
         if kind == "maxmag":
             assert net.is_exact               # accumulators can pass 2^24: float pipeline is selected
+        if kind == "wide":
+            assert not net.is_exact           # just inside the 24-bit operand range: integer requantiser
         for y in frames:
             rec_o, taps_o = _check_layered(net, mb, y)
             _check_fused(net, y, rec_o, taps_o["conc1"])
