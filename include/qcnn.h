@@ -100,6 +100,33 @@ int qcnn_batch_group(qcnn_t *e, int set, int *current);
  * (the role of MEM_DBG / viewmem, inference/cnn.cu:203-248). */
 int qcnn_forward_blu_layered(qcnn_t *e);
 
+/* ---- dynamic-quantisation path ---------------------------------------------------------- */
+/* qvrcnn::load_para(filename), inference/qvrcnn.cu:30-46 -> CovLayer::load_para, inference/cnn.cu:69-89:
+ * per layer an int32 step_w, the int8 weights (NCHW_VECT_C) and the int32 biases; 59 980 bytes.  The
+ * engine holds one model at a time: this replaces a static model and qcnn_load_static replaces this. */
+int qcnn_load_para(qcnn_t *e, const char *path);
+int qcnn_load_para_mem(qcnn_t *e, const void *image, size_t bytes);
+
+/* qvrcnn::forward(), inference/qvrcnn.cu:82-167: the pass whose activation steps are derived per frame
+ * from the largest |u| of every layer.  The shipped text of forward() calls quantize_out_static (:100),
+ * concat_blu (:122, :141) and adjustOutput_static(.., 141, 16) (:157), which read mul / shift / blu that
+ * load_para never sets; this entry point runs the alternatives the source keeps beside them --
+ * quantize_out (:98, inference/cnn.cu:169-178), concat (:121, :140, inference/cnn.cu:285-320) and
+ * adjustOutput(steps, ..) (:156) -- and everything else as written: adjustBasic before every
+ * convolution, no activation after C1, ReLU after C2_x / C3_x, insert_w / insert_y, applyRes.
+ * save_steps (:163) is a debug file append and is left to the caller.  Asynchronous on the engine
+ * stream: the step bookkeeping runs on the device, no maximum travels to the host. */
+int qcnn_forward(qcnn_t *e);
+
+/* Host copy of what the reference keeps in qvrcnn::steps and CovLayer::step_w / step_y / max_u / b_adj
+ * after forward() (synchronises the engine stream). */
+typedef struct {
+    int32_t stepw[4], stepy[4];                    /* step_parameters, inference/qvrcnn.cuh:11-15 */
+    int32_t step_w[QCNN_NUM_LAYERS], step_y[QCNN_NUM_LAYERS], max_u[QCNN_NUM_LAYERS];
+    float b_adj[161];                              /* 64, 32, 16, 16, 32, 1 concatenated */
+} qcnn_dynamic_state_t;
+int qcnn_dynamic_state(qcnn_t *e, qcnn_dynamic_state_t *out);
+
 /* cudaDeviceSynchronize() of inference/kernel.cu:95, restricted to the engine stream. */
 int qcnn_sync(qcnn_t *e);
 
@@ -135,7 +162,8 @@ enum {
     QCNN_TAP_X_REC = 10, /* uint8 [H][W]                 I1.x_rec                         */
     /* after qcnn_forward_blu (fused path): the one intermediate it keeps in HBM, converted
      * back to the reference layout of Conc1.conc */
-    QCNN_TAP_FUSED_CONC1 = 11
+    QCNN_TAP_FUSED_CONC1 = 11,
+    QCNN_TAP_V_C4 = 12   /* int8  [H][W]                 C4.v after qcnn_forward (adjustOutput)      */
 };
 int qcnn_tap_bytes(qcnn_t *e, int tap, size_t *bytes);
 int qcnn_tap(qcnn_t *e, int tap, void *host_out, size_t bytes);
@@ -186,6 +214,44 @@ int qcnn_op_quant_blu(const void *u, void *out, size_t hw, int channels, int blu
 
 /* InputLayer::applyRes_y / applyRes_GPU_y, inference/cnn.cu:507-535. */
 int qcnn_op_apply_res_y(const void *x, void *rec, const void *res, int mul, int shift, size_t n, void *stream);
+
+/* CovLayer::activate, inference/cnn.cu:161-166 (CUDNN_ACTIVATION_RELU, :57), in place on float u[n]. */
+int qcnn_op_activate(void *u, size_t n, void *stream);
+
+/* findMax, inference/mat.cu:28-96: *host_max = largest |u[i]|.  `workspace` is device memory (>= 4 bytes),
+ * the reference's `buffer`.  Blocking, like the reference's copy of the result to the host. */
+int qcnn_op_find_max(const void *u, void *workspace, size_t n, float *host_max, void *stream);
+
+/* CHW2CHW_VECT_C, inference/mat.cu:197-236 (NCHW2NCHW_VECT_C :237-247 per frame): float32
+ * (u -+ divisor/2) / divisor, clipped to [-128, 127], relayout.  u: float [channels][hw];
+ * out: int8 [channels/4][hw][4]. */
+int qcnn_op_quant_div(const void *u, void *out, size_t hw, int channels, int divisor, void *stream);
+
+/* mul_shift, inference/mat.cu:248-261 (CovLayer::quantize_out_static, inference/cnn.cu:189-194):
+ * out[i] = char((((int)u[i] + (1 << shift-1)/mul) * mul) >> shift), flat, no relayout. */
+int qcnn_op_mul_shift(const void *u, void *out, size_t n, int mul, int shift, void *stream);
+
+/* adjustBasic, inference/qvrcnn.cu:336-349: b_adj[i] = b[i] * stepw[0..n-1] / stepy[0..n-1], each
+ * division rounding half away from zero.  stepw / stepy: host int32[4]; b, b_adj: device float[count]. */
+int qcnn_op_adjust_basic(const int32_t *stepw, const int32_t *stepy, const void *b, void *b_adj, int count, int n,
+                         void *stream);
+
+/* adjustOutput, inference/qvrcnn.cu:368-385: o_adj[i] = char(o[i] * stepy[0..n-2] / stepw[n-1..0]).
+ * o: device float[num]; o_adj: device int8[num]. */
+int qcnn_op_adjust_output(const int32_t *stepw, const int32_t *stepy, const void *o, void *o_adj, int n, size_t num,
+                          void *stream);
+
+/* adjustOutput_static, inference/qvrcnn.cu:386-397: o_adj[i] = char(((int)o[i] * mul + (1 << shift-1)) >> shift). */
+int qcnn_op_adjust_output_static(const void *o, void *o_adj, int mul, int shift, size_t num, void *stream);
+
+/* InputLayer::applyRes / applyRes_GPU, inference/cnn.cu:487-502,524-529: rec = clamp((short)x + res),
+ * res int8[n]. */
+int qcnn_op_apply_res(const void *x, const void *res, void *rec, size_t n, void *stream);
+
+/* The step selection of ConcatLayer::concat, inference/cnn.cu:295-309 (host only): one step per branch
+ * from its own maximum (1 if the maximum fits in 127), then the finer branch coarsened so that
+ * step_w * step_y of both branches agree. */
+int qcnn_concat_steps(float max1, float max2, int step_w1, int step_w2, int *stepy1, int *stepy2);
 
 /* ---- device memory helpers for hosts that do not link HIP ------------------------------ */
 int qcnn_set_device(int gpu);

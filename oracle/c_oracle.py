@@ -21,9 +21,15 @@ class _Taps(C.Structure):
                 ("conc2", C.c_void_p)]
 
 
+class _DynTaps(C.Structure):
+    _fields_ = [("x_ppro", C.c_void_p), ("u", C.c_void_p * 6), ("v1", C.c_void_p), ("conc1", C.c_void_p),
+                ("conc2", C.c_void_p), ("v4", C.c_void_p), ("b_adj", C.c_void_p), ("max_u", C.c_void_p),
+                ("step_y", C.c_void_p), ("stepw", C.c_void_p), ("stepy", C.c_void_p)]
+
+
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "qcnn_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("qcnn_oracle.c", "qcnn_oracle_dyn.c")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libqcnn_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB
 
@@ -61,6 +67,32 @@ def lib():
         L.orc_quant_blu.restype = None
         L.orc_quant_blu.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_num_threads.restype = C.c_int
+        vp, i, f, lg = C.c_void_p, C.c_int, C.c_float, C.c_long
+        L.orc_dyn_model_bytes.restype = lg
+        L.orc_find_max.restype = f
+        L.orc_find_max.argtypes = [vp, lg]
+        L.orc_quant_div_one.restype = C.c_int8
+        L.orc_quant_div_one.argtypes = [f, i]
+        L.orc_quant_div.restype = None
+        L.orc_quant_div.argtypes = [vp, vp, lg, i, i]
+        L.orc_mul_shift.restype = None
+        L.orc_mul_shift.argtypes = [vp, vp, lg, i, i]
+        L.orc_adjust_basic.restype = None
+        L.orc_adjust_basic.argtypes = [vp, vp, vp, vp, i, i]
+        L.orc_adjust_output.restype = None
+        L.orc_adjust_output.argtypes = [vp, vp, vp, vp, i, lg]
+        L.orc_adjust_output_static.restype = None
+        L.orc_adjust_output_static.argtypes = [vp, vp, i, i, lg]
+        L.orc_apply_res.restype = None
+        L.orc_apply_res.argtypes = [vp, vp, vp, lg]
+        L.orc_quantize_out_step.restype = i
+        L.orc_quantize_out_step.argtypes = [f]
+        L.orc_concat_steps.restype = None
+        L.orc_concat_steps.argtypes = [f, f, i, i, C.POINTER(i), C.POINTER(i)]
+        L.orc_insert_w.argtypes = [vp, i, i]
+        L.orc_insert_y.argtypes = [vp, i, i]
+        L.orc_forward_dynamic.restype = i
+        L.orc_forward_dynamic.argtypes = [vp, lg, vp, i, i, vp, vp]
         L.orc_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
@@ -121,3 +153,35 @@ def model_hwcn2nchw_vect_c(hwcn: bytes) -> bytes:
     if n < 0:
         raise ValueError("orc_model_hwcn2nchw_vect_c failed")
     return dst[:n].tobytes()
+
+
+def forward_dynamic(model_bytes: bytes, y: np.ndarray, want_taps: bool = False):
+    """The dynamic-quantisation pass (oracle/qcnn_oracle_dyn.c): y uint8 [H][W] -> rec (and taps)."""
+    L = lib()
+    y = np.ascontiguousarray(y, np.uint8)
+    h, w = y.shape
+    rec = np.empty((h, w), np.uint8)
+    mb = np.frombuffer(model_bytes, np.uint8)
+    taps, tp = None, None
+    if want_taps:
+        taps = {
+            "x_ppro": np.empty((1, h, w, 4), np.int8),
+            "u": [np.empty((c, h, w), np.float32) for c in COUT],
+            "v1": np.empty((16, h, w, 4), np.int8),
+            "conc1": np.empty((12, h, w, 4), np.int8),
+            "conc2": np.empty((12, h, w, 4), np.int8),
+            "v4": np.empty((h, w), np.int8),
+            "b_adj": np.empty(161, np.float32),
+            "max_u": np.empty(6, np.int32), "step_y": np.empty(6, np.int32),
+            "stepw": np.empty(4, np.int32), "stepy": np.empty(4, np.int32),
+        }
+        t = _DynTaps()
+        for i in range(6):
+            t.u[i] = taps["u"][i].ctypes.data
+        for k in ("x_ppro", "v1", "conc1", "conc2", "v4", "b_adj", "max_u", "step_y", "stepw", "stepy"):
+            setattr(t, k, taps[k].ctypes.data)
+        tp = C.byref(t)
+    rc = L.orc_forward_dynamic(_p(mb), mb.size, _p(y), h, w, _p(rec), tp)
+    if rc:
+        raise ValueError(f"orc_forward_dynamic failed: {rc}")
+    return (rec, taps) if want_taps else rec

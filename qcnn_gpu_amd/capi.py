@@ -22,10 +22,20 @@ SYMBOLS = (
     "qcnn_op_quant_blu", "qcnn_op_apply_res_y", "qcnn_set_device", "qcnn_dev_alloc", "qcnn_dev_free", "qcnn_dev_h2d",
     "qcnn_dev_d2h", "qcnn_dev_memset", "qcnn_dev_sync", "qcnn_host_alloc_pinned", "qcnn_host_free_pinned",
     "qcnn_hwcn2nchw_vect_c", "qcnn_model_qfp_hwcn2nchw_vect_c",
+    # dynamic-quantisation path
+    "qcnn_load_para", "qcnn_load_para_mem", "qcnn_forward", "qcnn_dynamic_state", "qcnn_op_activate",
+    "qcnn_op_find_max", "qcnn_op_quant_div", "qcnn_op_mul_shift", "qcnn_op_adjust_basic", "qcnn_op_adjust_output",
+    "qcnn_op_adjust_output_static", "qcnn_op_apply_res", "qcnn_concat_steps",
 )
 
 TAP_X_PPRO, TAP_U_C1, TAP_U_C2_1, TAP_U_C2_2, TAP_U_C3_1, TAP_U_C3_2, TAP_U_C4 = range(7)
-TAP_V_C1, TAP_CONC1, TAP_CONC2, TAP_X_REC, TAP_FUSED_CONC1 = 7, 8, 9, 10, 11
+TAP_V_C1, TAP_CONC1, TAP_CONC2, TAP_X_REC, TAP_FUSED_CONC1, TAP_V_C4 = 7, 8, 9, 10, 11, 12
+
+
+class DynamicState(C.Structure):
+    """qcnn_dynamic_state_t of include/qcnn.h."""
+    _fields_ = [("stepw", C.c_int32 * 4), ("stepy", C.c_int32 * 4), ("step_w", C.c_int32 * 6),
+                ("step_y", C.c_int32 * 6), ("max_u", C.c_int32 * 6), ("b_adj", C.c_float * 161)]
 
 
 class QcnnError(RuntimeError):
@@ -100,6 +110,19 @@ def load():
     L.qcnn_hwcn2nchw_vect_c.restype = C.c_long
     L.qcnn_hwcn2nchw_vect_c.argtypes = [vp, i, i, i, i, vp]
     L.qcnn_model_qfp_hwcn2nchw_vect_c.argtypes = [C.c_char_p, C.c_char_p, i]
+    L.qcnn_load_para.argtypes = [vp, C.c_char_p]
+    L.qcnn_load_para_mem.argtypes = [vp, vp, sz]
+    L.qcnn_forward.argtypes = [vp]
+    L.qcnn_dynamic_state.argtypes = [vp, C.POINTER(DynamicState)]
+    L.qcnn_op_activate.argtypes = [vp, sz, vp]
+    L.qcnn_op_find_max.argtypes = [vp, vp, sz, C.POINTER(C.c_float), vp]
+    L.qcnn_op_quant_div.argtypes = [vp, vp, sz, i, i, vp]
+    L.qcnn_op_mul_shift.argtypes = [vp, vp, sz, i, i, vp]
+    L.qcnn_op_adjust_basic.argtypes = [vp, vp, vp, vp, i, i, vp]
+    L.qcnn_op_adjust_output.argtypes = [vp, vp, vp, vp, i, sz, vp]
+    L.qcnn_op_adjust_output_static.argtypes = [vp, vp, i, i, sz, vp]
+    L.qcnn_op_apply_res.argtypes = [vp, vp, vp, sz, vp]
+    L.qcnn_concat_steps.argtypes = [C.c_float, C.c_float, i, i, C.POINTER(i), C.POINTER(i)]
     _lib = L
     return L
 

@@ -72,6 +72,10 @@ struct qcnn_engine {
     float *u[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int8_t *v1 = nullptr, *conc1 = nullptr, *conc2 = nullptr;
     int8_t *w_file[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // CovLayer::w, file order
+    // dynamic-quantisation pass (qcnn_load_para / qcnn_forward)
+    bool dyn_loaded = false;
+    DynState *dyn = nullptr;  // device
+    int8_t *v4 = nullptr;     // C4.v: int8 residual [H][W]
     // model
     bool loaded = false;
     bool exact = false;  // true: float-pipeline kernels; false: integer fast path proved safe
@@ -266,6 +270,51 @@ static int load_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
     HIP_TRY(hipMemcpy(e->bias_f, bias_f.data(), 161 * sizeof(float), hipMemcpyHostToDevice));
     for (int l = 0; l < 6; ++l) HIP_TRY(hipMemcpy(e->w_file[l], L[l].w, wsize(l), hipMemcpyHostToDevice));
     e->loaded = true;
+    e->dyn_loaded = false;  // CovLayer::w now holds the static model
+    return QCNN_OK;
+}
+
+static size_t dyn_model_bytes()
+{
+    size_t n = 0;
+    for (int l = 0; l < 6; ++l) n += 4 + wsize(l) + 4 * L_COUT[l];
+    return n;
+}
+
+// qvrcnn::load_para (inference/qvrcnn.cu:30-46) -> CovLayer::load_para (inference/cnn.cu:69-89) per layer:
+// int32 step_w, wSize int8 weights (NCHW_VECT_C), outChannel int32 biases converted to float.
+static int load_dyn_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
+{
+    if (bytes < dyn_model_bytes())
+        return fail(QCNN_E_FORMAT, "dynamic model image is %zu bytes, expected %zu", bytes, dyn_model_bytes());
+    HIP_TRY(hipSetDevice(e->gpu));
+    std::vector<uint8_t> hostv(sizeof(DynState), 0);
+    DynState &st = *reinterpret_cast<DynState *>(hostv.data());
+    const uint8_t *p = img;
+    const uint8_t *wptr[6];
+    for (int l = 0; l < 6; ++l) {
+        int32_t sw;
+        memcpy(&sw, p, 4);
+        p += 4;
+        // a step divides in ConcatLayer::concat (inference/cnn.cu:305-307) and in adjustOutput
+        if (sw < 1) return fail(QCNN_E_FORMAT, "layer %d: step_w %d must be positive", l, sw);
+        st.step_w[l] = sw;
+        wptr[l] = p;
+        p += wsize(l);
+        for (int k = 0; k < L_COUT[l]; ++k) {
+            int32_t bi;
+            memcpy(&bi, p + 4 * k, 4);
+            st.b[BIAS_OFF[l] + k] = (float)bi;  // inference/cnn.cu:81
+        }
+        p += 4 * L_COUT[l];
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!e->dyn) HIP_TRY(hipMalloc(&e->dyn, sizeof(DynState)));
+    if (!e->v4) HIP_TRY(hipMalloc(&e->v4, e->HW));
+    HIP_TRY(hipMemcpy(e->dyn, &st, sizeof(DynState), hipMemcpyHostToDevice));
+    for (int l = 0; l < 6; ++l) HIP_TRY(hipMemcpy(e->w_file[l], wptr[l], wsize(l), hipMemcpyHostToDevice));
+    e->dyn_loaded = true;
+    e->loaded = false;  // CovLayer::w now holds the dynamic model
     return QCNN_OK;
 }
 
@@ -411,6 +460,8 @@ int qcnn_destroy(qcnn_t *e)
         (void)hipFree(e->w_file[l]);
     }
     (void)hipFree(e->v1);
+    (void)hipFree(e->dyn);
+    (void)hipFree(e->v4);
     (void)hipFree(e->conc1);
     (void)hipFree(e->conc2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -667,18 +718,99 @@ int qcnn_forward_blu_layered(qcnn_t *e)
     uint8_t *rec = e->bound_rec ? e->bound_rec : e->x_rec;
     // the call sequence of qvrcnn::forward_blu, inference/qvrcnn.cu:168-242
     HIP_TRY(launch_ppro(y, e->x_ppro, HW, s));
-    HIP_TRY(launch_conv_static(e->x_ppro, e->w_file[0], e->bias_f + BIAS_OFF[0], e->u[0], H, W, 1, 64, 5, s));
+    HIP_TRY(launch_conv_static(e->x_ppro, e->w_file[0], e->bias_f + BIAS_OFF[0], e->u[0], H, W, 1, 64, 5, 0, s));
     HIP_TRY(launch_quant_blu(e->u[0], e->v1, HW, 64, e->rq[0], s));
-    HIP_TRY(launch_conv_static(e->v1, e->w_file[1], e->bias_f + BIAS_OFF[1], e->u[1], H, W, 64, 32, 3, s));
-    HIP_TRY(launch_conv_static(e->v1, e->w_file[2], e->bias_f + BIAS_OFF[2], e->u[2], H, W, 64, 16, 5, s));
+    HIP_TRY(launch_conv_static(e->v1, e->w_file[1], e->bias_f + BIAS_OFF[1], e->u[1], H, W, 64, 32, 3, 0, s));
+    HIP_TRY(launch_conv_static(e->v1, e->w_file[2], e->bias_f + BIAS_OFF[2], e->u[2], H, W, 64, 16, 5, 0, s));
     HIP_TRY(launch_quant_blu(e->u[1], e->conc1, HW, 32, e->rq[1], s));
     HIP_TRY(launch_quant_blu(e->u[2], e->conc1 + 32 * HW, HW, 16, e->rq[2], s));
-    HIP_TRY(launch_conv_static(e->conc1, e->w_file[3], e->bias_f + BIAS_OFF[3], e->u[3], H, W, 48, 16, 3, s));
-    HIP_TRY(launch_conv_static(e->conc1, e->w_file[4], e->bias_f + BIAS_OFF[4], e->u[4], H, W, 48, 32, 1, s));
+    HIP_TRY(launch_conv_static(e->conc1, e->w_file[3], e->bias_f + BIAS_OFF[3], e->u[3], H, W, 48, 16, 3, 0, s));
+    HIP_TRY(launch_conv_static(e->conc1, e->w_file[4], e->bias_f + BIAS_OFF[4], e->u[4], H, W, 48, 32, 1, 0, s));
     HIP_TRY(launch_quant_blu(e->u[3], e->conc2, HW, 16, e->rq[3], s));
     HIP_TRY(launch_quant_blu(e->u[4], e->conc2 + 16 * HW, HW, 32, e->rq[4], s));
-    HIP_TRY(launch_conv_static(e->conc2, e->w_file[5], e->bias_f + BIAS_OFF[5], e->u[5], H, W, 48, 1, 3, s));
+    HIP_TRY(launch_conv_static(e->conc2, e->w_file[5], e->bias_f + BIAS_OFF[5], e->u[5], H, W, 48, 1, 3, 0, s));
     HIP_TRY(launch_apply_res_y(y, rec, e->u[5], e->rq[5].mul, e->rq[5].shift, HW, s));
+    return QCNN_OK;
+}
+
+int qcnn_load_para_mem(qcnn_t *e, const void *image, size_t bytes)
+{
+    if (!e || !image) return fail(QCNN_E_ARG, "null argument");
+    return load_dyn_image(e, static_cast<const uint8_t *>(image), bytes);
+}
+
+int qcnn_load_para(qcnn_t *e, const char *path)
+{
+    if (!e || !path) return fail(QCNN_E_ARG, "null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(QCNN_E_IO, "cannot open model file %s", path);
+    std::vector<uint8_t> buf(dyn_model_bytes());
+    const size_t got = fread(buf.data(), 1, buf.size(), fp);
+    fclose(fp);
+    if (got != buf.size()) return fail(QCNN_E_FORMAT, "%s: short model file (%zu of %zu bytes)", path, got, buf.size());
+    return load_dyn_image(e, buf.data(), buf.size());
+}
+
+// qvrcnn::forward (inference/qvrcnn.cu:82-167) with quantize_out / concat / adjustOutput in the places
+// where the shipped text calls their static counterparts (see include/qcnn.h).  The host bookkeeping
+// between the layers runs on the device (k_dyn_book), so nothing here waits for the GPU.
+int qcnn_forward(qcnn_t *e)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    if (!e->dyn_loaded) return fail(QCNN_E_STATE, "forward before load_para");
+    int rc = ensure_layered(e);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->gpu));
+    hipStream_t s = e->stream;
+    const int H = e->H, W = e->W;
+    const size_t HW = e->HW;
+    const uint8_t *y = e->bound_y ? e->bound_y : e->x;
+    uint8_t *rec = e->bound_rec ? e->bound_rec : e->x_rec;
+    DynState *st = e->dyn;
+    const float *badj = st->b_adj;  // device addresses; never dereferenced on the host
+    HIP_TRY(launch_dyn_book(st, 0, s));
+    HIP_TRY(launch_ppro(y, e->x_ppro, HW, s));
+    // layer 1: no activation (inference/qvrcnn.cu:96 is commented out)
+    HIP_TRY(launch_conv_static(e->x_ppro, e->w_file[0], badj + BIAS_OFF[0], e->u[0], H, W, 1, 64, 5, 0, s));
+    HIP_TRY(launch_absmax(e->u[0], 64 * HW, &st->maxbits[0], s));
+    HIP_TRY(launch_dyn_book(st, 1, s));
+    HIP_TRY(launch_quant_div(e->u[0], e->v1, HW, 64, 0, &st->step_y[0], s));
+    // layer 2
+    HIP_TRY(launch_conv_static(e->v1, e->w_file[1], badj + BIAS_OFF[1], e->u[1], H, W, 64, 32, 3, 1, s));
+    HIP_TRY(launch_conv_static(e->v1, e->w_file[2], badj + BIAS_OFF[2], e->u[2], H, W, 64, 16, 5, 1, s));
+    HIP_TRY(launch_absmax(e->u[1], 32 * HW, &st->maxbits[1], s));
+    HIP_TRY(launch_absmax(e->u[2], 16 * HW, &st->maxbits[2], s));
+    HIP_TRY(launch_dyn_book(st, 2, s));
+    HIP_TRY(launch_quant_div(e->u[1], e->conc1, HW, 32, 0, &st->step_y[1], s));
+    HIP_TRY(launch_quant_div(e->u[2], e->conc1 + 32 * HW, HW, 16, 0, &st->step_y[2], s));
+    // layer 3
+    HIP_TRY(launch_conv_static(e->conc1, e->w_file[3], badj + BIAS_OFF[3], e->u[3], H, W, 48, 16, 3, 1, s));
+    HIP_TRY(launch_conv_static(e->conc1, e->w_file[4], badj + BIAS_OFF[4], e->u[4], H, W, 48, 32, 1, 1, s));
+    HIP_TRY(launch_absmax(e->u[3], 16 * HW, &st->maxbits[3], s));
+    HIP_TRY(launch_absmax(e->u[4], 32 * HW, &st->maxbits[4], s));
+    HIP_TRY(launch_dyn_book(st, 3, s));
+    HIP_TRY(launch_quant_div(e->u[3], e->conc2, HW, 16, 0, &st->step_y[3], s));
+    HIP_TRY(launch_quant_div(e->u[4], e->conc2 + 16 * HW, HW, 32, 0, &st->step_y[4], s));
+    // layer 4 and restore
+    HIP_TRY(launch_conv_static(e->conc2, e->w_file[5], badj + BIAS_OFF[5], e->u[5], H, W, 48, 1, 3, 0, s));
+    HIP_TRY(launch_dyn_book(st, 4, s));
+    HIP_TRY(launch_adjust_output(DynSteps(), &st->steps, e->u[5], e->v4, 4, HW, s));
+    HIP_TRY(launch_apply_res(y, e->v4, rec, HW, s));
+    return QCNN_OK;
+}
+
+int qcnn_dynamic_state(qcnn_t *e, qcnn_dynamic_state_t *out)
+{
+    if (!e || !out) return fail(QCNN_E_ARG, "null argument");
+    if (!e->dyn_loaded) return fail(QCNN_E_STATE, "no dynamic model loaded");
+    HIP_TRY(hipSetDevice(e->gpu));
+    std::vector<uint8_t> hostv(sizeof(DynState));
+    HIP_TRY(hipMemcpyAsync(hostv.data(), e->dyn, sizeof(DynState), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const DynState &st = *reinterpret_cast<const DynState *>(hostv.data());
+    for (int k = 0; k < 4; ++k) out->stepw[k] = st.steps.stepw[k], out->stepy[k] = st.steps.stepy[k];
+    for (int l = 0; l < 6; ++l) out->step_w[l] = st.step_w[l], out->step_y[l] = st.step_y[l], out->max_u[l] = st.max_u[l];
+    memcpy(out->b_adj, st.b_adj, sizeof st.b_adj);
     return QCNN_OK;
 }
 
@@ -746,6 +878,9 @@ static int tap_info(qcnn_t *e, int tap, void **dev, size_t *bytes)
     case QCNN_TAP_CONC2: *dev = e->conc2; *bytes = 48 * HW; return 0;
     case QCNN_TAP_X_REC: *dev = e->bound_rec ? e->bound_rec : e->x_rec; *bytes = HW; return 0;
     case QCNN_TAP_FUSED_CONC1: *dev = e->conc1_int; *bytes = 48 * HW; return 0;
+    case QCNN_TAP_V_C4:
+        if (!e->v4) return fail(QCNN_E_STATE, "C4.v exists only after load_para");
+        *dev = e->v4; *bytes = HW; return 0;
     default: return fail(QCNN_E_ARG, "unknown tap %d", tap);
     }
 }
@@ -865,7 +1000,7 @@ int qcnn_op_conv_static(const void *x, const void *w, const void *b, void *u, in
     if (!x || !w || !b || !u) return fail(QCNN_E_ARG, "null argument");
     if (height < 1 || width < 1 || cin < 1 || cout < 1) return fail(QCNN_E_ARG, "bad conv shape");
     if (ks != 1 && ks != 3 && ks != 5) return fail(QCNN_E_UNSUPPORTED, "ksize %d (1, 3 or 5)", ks);
-    HIP_TRY(launch_conv_static(x, w, b, u, height, width, cin, cout, ks, (hipStream_t)stream));
+    HIP_TRY(launch_conv_static(x, w, b, u, height, width, cin, cout, ks, 0, (hipStream_t)stream));
     return QCNN_OK;
 }
 
@@ -882,6 +1017,98 @@ int qcnn_op_apply_res_y(const void *x, void *rec, const void *res, int mul, int 
     if (!x || !rec || !res) return fail(QCNN_E_ARG, "null argument");
     if (shift < 1 || shift > 31) return fail(QCNN_E_ARG, "bad shift %d", shift);
     HIP_TRY(launch_apply_res_y(x, rec, res, mul, shift, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_activate(void *u, size_t n, void *stream)
+{
+    if (!u) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(launch_relu(u, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_find_max(const void *u, void *workspace, size_t n, float *host_max, void *stream)
+{
+    if (!u || !workspace || !host_max) return fail(QCNN_E_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(workspace, 0, sizeof(unsigned), s));
+    HIP_TRY(launch_absmax(u, n, (unsigned *)workspace, s));
+    HIP_TRY(hipMemcpyAsync(host_max, workspace, sizeof(float), hipMemcpyDeviceToHost, s));  // mat.cu:34
+    HIP_TRY(hipStreamSynchronize(s));
+    return QCNN_OK;
+}
+
+int qcnn_op_quant_div(const void *u, void *out, size_t hw, int channels, int divisor, void *stream)
+{
+    if (!u || !out) return fail(QCNN_E_ARG, "null argument");
+    if (divisor == 0 || channels < 1) return fail(QCNN_E_ARG, "bad divisor %d / channels %d", divisor, channels);
+    HIP_TRY(launch_quant_div(u, out, hw, channels, divisor, nullptr, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_mul_shift(const void *u, void *out, size_t n, int mul, int shift, void *stream)
+{
+    if (!u || !out) return fail(QCNN_E_ARG, "null argument");
+    if (mul <= 0 || shift < 1 || shift > 31) return fail(QCNN_E_ARG, "bad requant parameters");
+    HIP_TRY(launch_mul_shift(u, out, n, mul, shift, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+static int copy_steps(const int32_t *stepw, const int32_t *stepy, int n_w, int n_y, DynSteps *st)
+{
+    if (!stepw || !stepy) return fail(QCNN_E_ARG, "null argument");
+    for (int k = 0; k < 4; ++k) st->stepw[k] = stepw[k], st->stepy[k] = stepy[k];
+    for (int k = 0; k < n_w; ++k)
+        if (stepw[k] == 0) return fail(QCNN_E_ARG, "stepw[%d] is 0", k);
+    for (int k = 0; k < n_y; ++k)
+        if (stepy[k] == 0) return fail(QCNN_E_ARG, "stepy[%d] is 0", k);
+    return QCNN_OK;
+}
+
+int qcnn_op_adjust_basic(const int32_t *stepw, const int32_t *stepy, const void *b, void *b_adj, int count, int n,
+                         void *stream)
+{
+    if (!b || !b_adj) return fail(QCNN_E_ARG, "null argument");
+    if (n < 0 || n > 4 || count < 0) return fail(QCNN_E_ARG, "bad n %d / count %d", n, count);
+    DynSteps st;
+    int rc = copy_steps(stepw, stepy, 0, n, &st);  // only stepy divides here
+    if (rc) return rc;
+    HIP_TRY(launch_adjust_basic(st, b, b_adj, count, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_adjust_output(const int32_t *stepw, const int32_t *stepy, const void *o, void *o_adj, int n, size_t num,
+                          void *stream)
+{
+    if (!o || !o_adj) return fail(QCNN_E_ARG, "null argument");
+    if (n < 1 || n > 4) return fail(QCNN_E_ARG, "bad n %d", n);
+    DynSteps st;
+    int rc = copy_steps(stepw, stepy, n, 0, &st);  // only stepw divides here
+    if (rc) return rc;
+    HIP_TRY(launch_adjust_output(st, nullptr, o, o_adj, n, num, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_adjust_output_static(const void *o, void *o_adj, int mul, int shift, size_t num, void *stream)
+{
+    if (!o || !o_adj) return fail(QCNN_E_ARG, "null argument");
+    if (shift < 1 || shift > 31) return fail(QCNN_E_ARG, "bad shift %d", shift);
+    HIP_TRY(launch_adjust_output_static(o, o_adj, mul, shift, num, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_apply_res(const void *x, const void *res, void *rec, size_t n, void *stream)
+{
+    if (!x || !res || !rec) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(launch_apply_res(x, res, rec, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_concat_steps(float max1, float max2, int step_w1, int step_w2, int *stepy1, int *stepy2)
+{
+    if (!stepy1 || !stepy2) return fail(QCNN_E_ARG, "null argument");
+    if (step_w1 < 1 || step_w2 < 1) return fail(QCNN_E_ARG, "weight steps must be positive");
+    concat_steps(max1, max2, step_w1, step_w2, stepy1, stepy2);
     return QCNN_OK;
 }
 

@@ -38,11 +38,12 @@ __global__ __launch_bounds__(256) void k_ppro(const uint8_t *__restrict__ x, uin
 
 // CovLayer::ConvForward_static (inference/cnn.cu:145-160) as a direct convolution on the
 // NCHW_VECT_C layout: each thread owns one output pixel and KB output channels, one v_dot4 per
-// (vec4 of input channels, tap, output channel).  u = float(acc) + b.
+// (vec4 of input channels, tap, output channel).  u = float(acc) + b; with relu != 0 negative results
+// are stored as 0 (CovLayer::activate, inference/cnn.cu:161-166, which the dynamic pass runs on u).
 template <int KS, int KB>
 __global__ __launch_bounds__(256) void k_conv_static(const int *__restrict__ x, const int *__restrict__ w,
                                                      const float *__restrict__ b, float *__restrict__ u, int H,
-                                                     int W, int C4, int K)
+                                                     int W, int C4, int K, int relu)
 {
     constexpr int P = (KS - 1) / 2;
     const int xo = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -70,34 +71,38 @@ __global__ __launch_bounds__(256) void k_conv_static(const int *__restrict__ x, 
         }
     }
 #pragma unroll
-    for (int i = 0; i < KB; ++i) u[((size_t)(k0 + i) * H + yo) * W + xo] = (float)acc[i] + b[k0 + i];
+    for (int i = 0; i < KB; ++i) {
+        float v = (float)acc[i] + b[k0 + i];
+        if (relu && v < 0.f) v = 0.f;
+        u[((size_t)(k0 + i) * H + yo) * W + xo] = v;
+    }
 }
 
 template <int KS>
 static hipError_t conv_dispatch(const void *x, const void *w, const void *b, void *u, int H, int W, int cin,
-                                int cout, hipStream_t s)
+                                int cout, int relu, hipStream_t s)
 {
     const int C4 = (cin + 3) / 4;
     dim3 block(256);
     if (cout % 8 == 0) {
         dim3 grid((W + 63) / 64, (H + 3) / 4, cout / 8);
         hipLaunchKernelGGL((k_conv_static<KS, 8>), grid, block, 0, s, (const int *)x, (const int *)w,
-                           (const float *)b, (float *)u, H, W, C4, cout);
+                           (const float *)b, (float *)u, H, W, C4, cout, relu);
     } else {
         dim3 grid((W + 63) / 64, (H + 3) / 4, cout);
         hipLaunchKernelGGL((k_conv_static<KS, 1>), grid, block, 0, s, (const int *)x, (const int *)w,
-                           (const float *)b, (float *)u, H, W, C4, cout);
+                           (const float *)b, (float *)u, H, W, C4, cout, relu);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_conv_static(const void *x, const void *w, const void *b, void *u, int H, int W, int cin,
-                              int cout, int ks, hipStream_t s)
+                              int cout, int ks, int relu, hipStream_t s)
 {
     switch (ks) {
-    case 1: return conv_dispatch<1>(x, w, b, u, H, W, cin, cout, s);
-    case 3: return conv_dispatch<3>(x, w, b, u, H, W, cin, cout, s);
-    case 5: return conv_dispatch<5>(x, w, b, u, H, W, cin, cout, s);
+    case 1: return conv_dispatch<1>(x, w, b, u, H, W, cin, cout, relu, s);
+    case 3: return conv_dispatch<3>(x, w, b, u, H, W, cin, cout, relu, s);
+    case 5: return conv_dispatch<5>(x, w, b, u, H, W, cin, cout, relu, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -115,10 +115,41 @@ __host__ __device__ inline int kb_pixel_of_lane(int c)  // c = lane & 15 -> colu
     return (c >= 4 && c < 12) ? 2 * (c - 4) : c < 4 ? 2 * c + 1 : 2 * (c - 12) + 9;
 }
 
+// ---- dynamic-quantisation pass ----------------------------------------------------------------
+// step_parameters of inference/qvrcnn.cuh:11-15: stepw kept in descending, stepy in ascending order.
+struct DynSteps {
+    int stepw[4];
+    int stepy[4];
+};
+// Device-resident bookkeeping of one pass of qvrcnn::forward (what the reference keeps in host members:
+// steps, CovLayer::step_w / step_y / max_u, and the device arrays CovLayer::b / b_adj).
+struct DynState {
+    DynSteps steps;
+    int step_w[QCNN_NUM_LAYERS];        // from the model file (CovLayer::load_para, inference/cnn.cu:78)
+    int step_y[QCNN_NUM_LAYERS];
+    int max_u[QCNN_NUM_LAYERS];
+    unsigned maxbits[QCNN_NUM_LAYERS];  // largest |u| of each layer as float bits
+    float b[161];                       // biases as loaded, layers concatenated (BIAS_OFF)
+    float b_adj[161];                   // adjustBasic output
+};
+
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------
 hipError_t launch_ppro(const void *x, void *x_ppro, size_t n, hipStream_t s);
+// relu != 0 applies CovLayer::activate (inference/cnn.cu:161-166) to the result before it is stored
 hipError_t launch_conv_static(const void *x, const void *w, const void *b, void *u, int H, int W, int cin,
-                              int cout, int ks, hipStream_t s);
+                              int cout, int ks, int relu, hipStream_t s);
+hipError_t launch_absmax(const void *u, size_t n, unsigned *maxbits, hipStream_t s);
+hipError_t launch_relu(void *u, size_t n, hipStream_t s);
+hipError_t launch_quant_div(const void *u, void *out, size_t hw, int channels, int divisor, const int *divisor_dev,
+                            hipStream_t s);
+hipError_t launch_mul_shift(const void *in, void *out, size_t n, int mul, int shift, hipStream_t s);
+hipError_t launch_adjust_basic(const DynSteps &st, const void *b, void *b_adj, int count, int n, hipStream_t s);
+hipError_t launch_adjust_output(const DynSteps &st, const DynSteps *st_dev, const void *o, void *o_adj, int n,
+                                size_t num, hipStream_t s);
+hipError_t launch_adjust_output_static(const void *o, void *o_adj, int mul, int shift, size_t num, hipStream_t s);
+hipError_t launch_apply_res(const void *x, const void *res, void *rec, size_t n, hipStream_t s);
+hipError_t launch_dyn_book(DynState *st, int stage, hipStream_t s);
+void concat_steps(float max1, float max2, int sw1, int sw2, int *stepy1, int *stepy2);
 hipError_t launch_quant_blu(const void *u, void *out, size_t hw, int channels, const Requant &rq, hipStream_t s);
 hipError_t launch_apply_res_y(const void *x, void *rec, const void *res, int mul, int shift, size_t n,
                               hipStream_t s);

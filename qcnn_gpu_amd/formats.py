@@ -129,6 +129,61 @@ class StaticModel:
 
 
 # ---------------------------------------------------------------------------------------
+# Dynamic-quantisation model: what CovLayer::load_para reads (inference/cnn.cu:69-89), layer by layer in
+# the order of qvrcnn::load_para (inference/qvrcnn.cu:38-43): int32 step_w, wSize int8 weights in
+# NCHW_VECT_C order, outChannel int32 biases.  It is the output format of model_HWCN2NCHW_VECT_C
+# (inference/qvrcnn.cu:398-443).
+MODEL_DYNAMIC_BYTES = sum(4 + layer_wsize(l) + 4 * LAYERS[l][3] for l in range(6))  # 59 980
+
+
+@dataclass
+class DynamicLayerParams:
+    w: np.ndarray      # int8 [k][c][r][s]
+    b: np.ndarray      # int32 [k]
+    step_w: int
+
+
+@dataclass
+class DynamicModel:
+    layers: List[DynamicLayerParams] = field(default_factory=list)
+
+    def to_bytes(self) -> bytes:
+        out = bytearray()
+        for l, lp in enumerate(self.layers):
+            _, ks, cin, cout = LAYERS[l]
+            assert lp.w.shape == (cout, cin, ks, ks) and lp.w.dtype == np.int8
+            out += struct.pack("<i", lp.step_w)
+            wv = np.zeros((cout, pad4(cin) // 4, ks, ks, 4), np.int8)
+            for c in range(cin):
+                wv[:, c >> 2, :, :, c & 3] = lp.w[:, c]
+            out += wv.tobytes()
+            out += np.asarray(lp.b, "<i4").tobytes()
+        assert len(out) == MODEL_DYNAMIC_BYTES
+        return bytes(out)
+
+    @staticmethod
+    def from_bytes(buf: bytes) -> "DynamicModel":
+        if len(buf) < MODEL_DYNAMIC_BYTES:
+            raise ValueError(f"dynamic model image too short: {len(buf)} < {MODEL_DYNAMIC_BYTES}")
+        m = DynamicModel()
+        off = 0
+        for l in range(6):
+            _, ks, cin, cout = LAYERS[l]
+            (step_w,) = struct.unpack_from("<i", buf, off)
+            off += 4
+            n = layer_wsize(l)
+            wv = np.frombuffer(buf, np.int8, n, off).reshape(cout, pad4(cin) // 4, ks, ks, 4)
+            off += n
+            w = np.empty((cout, cin, ks, ks), np.int8)
+            for c in range(cin):
+                w[:, c] = wv[:, c >> 2, :, :, c & 3]
+            b = np.frombuffer(buf, "<i4", cout, off).astype(np.int32)
+            off += 4 * cout
+            m.layers.append(DynamicLayerParams(w, b, step_w))
+        return m
+
+
+# ---------------------------------------------------------------------------------------
 # quant_params%d.data : a pickle of 6 lists of 6 numbers.  It is parsed here by hand from
 # the opcode stream (pickletools.genops only tokenises); nothing from the file is imported,
 # called or constructed.  The only REDUCE accepted is numpy's scalar reconstructor applied to

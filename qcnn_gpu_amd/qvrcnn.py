@@ -31,6 +31,7 @@ _TAP_SHAPES = {
     capi.TAP_CONC2: (np.int8, lambda h, w: (12, h, w, 4)),
     capi.TAP_X_REC: (np.uint8, lambda h, w: (h, w)),
     capi.TAP_FUSED_CONC1: (np.int8, lambda h, w: (12, h, w, 4)),
+    capi.TAP_V_C4: (np.int8, lambda h, w: (h, w)),
 }
 
 
@@ -61,6 +62,26 @@ class qvrcnn:
     def forward_blu(self) -> int:
         capi.check(self._lib.qcnn_forward_blu(self._h))
         return 0
+
+    def load_para(self, filename) -> int:
+        """qvrcnn::load_para (inference/qvrcnn.cu:30-46): the dynamic-quantisation model."""
+        if isinstance(filename, (bytes, bytearray, memoryview)) and len(filename) > 4096:
+            buf = bytes(filename)
+            capi.check(self._lib.qcnn_load_para_mem(self._h, buf, len(buf)))
+        else:
+            name = filename if isinstance(filename, bytes) else str(filename).encode()
+            capi.check(self._lib.qcnn_load_para(self._h, name))
+        return 0
+
+    def forward(self) -> int:
+        """qvrcnn::forward (inference/qvrcnn.cu:82-167), the dynamic-quantisation pass."""
+        capi.check(self._lib.qcnn_forward(self._h))
+        return 0
+
+    def dynamic_state(self) -> "capi.DynamicState":
+        st = capi.DynamicState()
+        capi.check(self._lib.qcnn_dynamic_state(self._h, C.byref(st)))
+        return st
 
     # -- additions ---------------------------------------------------------------------------
     def forward_blu_layered(self) -> int:

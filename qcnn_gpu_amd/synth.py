@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .formats import LAYERS, LayerParams, StaticModel
+from .formats import LAYERS, DynamicLayerParams, DynamicModel, LayerParams, StaticModel
 
 # (blu_q, mul, shift) per layer, decoded from training/quant_params{22,27,32,37}.data
 # (columns 4-6 of each row written by training/quantization.py:31,49,53).
@@ -99,6 +99,24 @@ def synth_model(qp: int = 37, seed: int = 0x4D4F444C, sigma_q4=None, triples=Non
             b = b // 16
         m.layers.append(LayerParams(w, b.astype(np.int32), int(blu), int(mul), int(shift)))
     return m
+
+
+# Weight steps of the synthetic dynamic-quantisation models (CovLayer::step_w, inference/cnn.cu:78).  The
+# two branches of a concat get different steps so that ConcatLayer::concat has to reconcile them, and
+# the product is large enough for adjustOutput to leave residuals of a few grey levels.
+_STEP_W = {
+    22: (48, 150, 181, 160, 210, 260),
+    27: (56, 181, 150, 190, 170, 280),
+    32: (64, 170, 150, 210, 160, 300),
+    37: (64, 181, 150, 210, 160, 300),
+}
+
+
+def synth_dynamic_model(qp: int = 37, step_w=None) -> DynamicModel:
+    """The weights and biases of synth_model(qp) with a weight step per layer (dynamic model file)."""
+    sw = step_w or _STEP_W[qp]
+    m = synth_model(qp)
+    return DynamicModel([DynamicLayerParams(lp.w, lp.b, int(s)) for lp, s in zip(m.layers, sw)])
 
 
 def adversarial_model(kind: str) -> StaticModel:
