@@ -1,11 +1,10 @@
 /*
  * cnn.h -- the reference's layer API (inference/cnn.cuh:17-100) on top of the C ABI of qcnn.h.
  * Same class names, same public members, same method names and argument meaning; the
- * cudnnHandle_t / cudnnTensorDescriptor_t parameters are the stand-ins of mat.h.  Only the
- * members of the static-quantised path are functional (load_static_para, ConvForward_static,
- * quantize_out_blu, concat_blu, ppro, applyRes_y); the dynamic-quantisation members of the
- * reference (load_para, ConvForward, quantize_out, concat ...) are declared and report
- * "unsupported" through check().
+ * cudnnHandle_t / cudnnTensorDescriptor_t parameters are the stand-ins of mat.h.  Both the
+ * static-quantised members (load_static_para, ConvForward_static, quantize_out_blu, concat_blu,
+ * ppro, applyRes_y) and the dynamic-quantisation members (load_para, ConvForward, activate,
+ * quantize_out, quantize_out_fix, quantize_out_static, concat, concat_fix, applyRes) are functional.
  */
 #ifndef QCNN_CNN_H
 #define QCNN_CNN_H
@@ -21,16 +20,16 @@ public:
     CovLayer();
     int build(qcnnHandle_t handle, qcnnTensorDescriptor_t xDesc, int batch, int height, int width, int inChannel,
               int outChannel, int ksize);                                  /* inference/cnn.cu:13-66 */
-    int load_para(FILE *fp);                                               /* dynamic path: unsupported */
+    int load_para(FILE *fp);                                               /* inference/cnn.cu:69-89 */
     int load_static_para(FILE *fp);                                        /* inference/cnn.cu:90-112 */
     int ConvForward(qcnnHandle_t handle, qcnnTensorDescriptor_t xDesc, void *x, void *workspace,
-                    size_t workspaceSize);                                 /* dynamic path: unsupported */
+                    size_t workspaceSize);                                 /* inference/cnn.cu:129-144 */
     int ConvForward_static(qcnnHandle_t handle, qcnnTensorDescriptor_t xDesc, void *x, void *workspace,
                            size_t workspaceSize);                          /* inference/cnn.cu:145-160 */
-    int activate(qcnnHandle_t handle);                                     /* unsupported */
-    int quantize_out(void *workspace);                                     /* unsupported */
-    int quantize_out_fix(int max_u);                                       /* unsupported */
-    int quantize_out_static(void);                                         /* unsupported */
+    int activate(qcnnHandle_t handle);                                     /* inference/cnn.cu:161-166 */
+    int quantize_out(void *workspace);                                     /* inference/cnn.cu:169-178 */
+    int quantize_out_fix(int max_u);                                       /* inference/cnn.cu:179-188 */
+    int quantize_out_static(void);                                         /* inference/cnn.cu:189-194 */
     int quantize_out_blu(void);                                            /* inference/cnn.cu:195-200 */
     int viewmem(xwtype *x);                                                /* inference/cnn.cu:203-248 */
     /* adopt buffers owned by a qcnn engine instead of allocating (used by class qvrcnn) */
@@ -59,7 +58,8 @@ class ConcatLayer {
 public:
     ConcatLayer(void);
     int build(int batch, int height, int width, int inChannel1, int inChannel2);   /* inference/cnn.cu:268-283 */
-    int concat(CovLayer *C1, CovLayer *C2, void *workspace);                        /* unsupported */
+    int concat(CovLayer *C1, CovLayer *C2, void *workspace);                        /* inference/cnn.cu:285-320 */
+    int concat_fix(CovLayer *C1, CovLayer *C2, convtype max1, convtype max2);       /* inference/cnn.cu:321-353 */
     int concat_blu(CovLayer *C1, CovLayer *C2);                                     /* inference/cnn.cu:375-394 */
     int adopt(int batch, int height, int width, int inChannel1, int inChannel2, void *conc);
     ~ConcatLayer();
@@ -78,7 +78,7 @@ public:
     int build(int batch, int channel, int height, int width);      /* inference/cnn.cu:414-438 */
     int load(datatype *input);                                      /* inference/cnn.cu:439-443 */
     int ppro(void);                                                 /* inference/cnn.cu:454-468 */
-    int applyRes(xwtype *res);                                      /* unsupported */
+    int applyRes(xwtype *res);                                      /* inference/cnn.cu:524-529 */
     int applyRes_y(convtype *res, int mul, int shift);              /* inference/cnn.cu:530-535 */
     int adopt(int batch, int channel, int height, int width, void *x, void *x_ppro, void *x_rec);
     ~InputLayer(void);

@@ -46,4 +46,9 @@ char *HWCN2NCHW_VECT_C_CPU(char *HWCN, int H, int W, int C, int N, int *outSize)
 int NCHW2NCHW_VECT_C_QUANT_BLU(convtype *before, xwtype *after, int N, int C, int H, int W, int blu, int multiplier,
                                int shifts);
 
+/* findMax, inference/mat.cu:28-35: *max = largest |data[i]|; `buffer` is device scratch (>= 4 bytes). */
+void findMax(convtype *data, convtype *buffer, int n, convtype *max);
+/* NCHW2NCHW_VECT_C, inference/mat.cu:237-247, on device pointers. */
+int NCHW2NCHW_VECT_C(convtype *dividend, xwtype *quotient, int divisor, int N, int C, int H, int W);
+
 #endif

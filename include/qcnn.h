@@ -172,9 +172,12 @@ void *qcnn_tap_device_ptr(qcnn_t *e, int tap);
 
 /* blu, mul, shift of layer l as loaded (CovLayer::blu/mul/shift, inference/cnn.cuh:49-50). */
 int qcnn_layer_params(qcnn_t *e, int layer, int *blu, int *mul, int *shift);
-/* Device addresses of layer l's weights (file order, int8) and float biases (CovLayer::w/b). */
+/* Device addresses of layer l's weights (file order, int8) and float biases (CovLayer::w/b) of the
+ * model loaded last (static or dynamic), and of the adjusted biases qcnn_forward computes
+ * (CovLayer::b_adj, inference/cnn.cu:62). */
 void *qcnn_layer_w_device_ptr(qcnn_t *e, int layer);
 void *qcnn_layer_b_device_ptr(qcnn_t *e, int layer);
+void *qcnn_layer_b_adj_device_ptr(qcnn_t *e, int layer);
 
 /* Arithmetic of the fused kernels.  At every load the engine proves from the weights whether the
  * reference's float32 accumulator pipeline (inference/cnn.cu:148-155, inference/mat.cu:275-291)

@@ -19,7 +19,14 @@
 typedef struct {
     int stepw[LAYER];
     int stepy[LAYER];
-} step_parameters; /* inference/qvrcnn.cuh:10-15; unused on the static path */
+} step_parameters; /* inference/qvrcnn.cuh:10-15: stepw descending, stepy ascending */
+
+/* Host-callable forms of the reference's bookkeeping kernels (inference/qvrcnn.cuh:21-23), which it
+ * launches as adjustBasic<<<1, outChannel>>>(..) etc.; here the element count is an argument.
+ * b / b_adj / o / o_adj are device pointers. */
+int adjustBasic(step_parameters steps, btype *b, btype *b_adj, int count, int n);
+int adjustOutput(step_parameters steps, convtype *o, xwtype *o_adj, int n, int num);
+int adjustOutput_static(convtype *o, xwtype *o_adj, int multiplier, int shifts, int num);
 
 /* model_qfp_HWCN2NCHW_VECT_C, inference/qvrcnn.cu:558-585 */
 int model_qfp_HWCN2NCHW_VECT_C(const char *filein, const char *fileout, int qp);
@@ -27,15 +34,20 @@ int model_qfp_HWCN2NCHW_VECT_C(const char *filein, const char *fileout, int qp);
 class qvrcnn {
 public:
     qvrcnn(int gpu_num, int batch, int channel, int height, int width); /* inference/qvrcnn.cu:4-29 */
-    int load_para(char *filename);                                      /* dynamic path: unsupported */
+    int load_para(char *filename);                                      /* inference/qvrcnn.cu:30-46 */
     int load_static_para(char *filename);                               /* inference/qvrcnn.cu:47-63 */
     int load_data(datatype *input);                                     /* inference/qvrcnn.cu:64-68 */
-    int forward(void);                                                  /* dynamic path: unsupported */
+    /* inference/qvrcnn.cu:82-167 with quantize_out / concat / adjustOutput (see qcnn_forward in qcnn.h);
+     * one asynchronous sequence of kernels, then steps / step_y / max_u are copied back into the members */
+    int forward(void);
+    /* the same pass issued call by call through the layer objects, with the host round trips of the
+     * reference (findMax copies every maximum to the host) */
+    int forward_layers(void);
     int forward_blu(void);       /* inference/qvrcnn.cu:168-242, as the two fused gfx950 kernels */
     /* the same pass issued call by call through the layer objects, in the order and with the
      * buffers of inference/qvrcnn.cu:168-242 (every u / v / conc is materialised) */
     int forward_blu_layers(void);
-    int save_b_adj(const char *filename);                               /* unsupported */
+    int save_b_adj(const char *filename);                               /* inference/qvrcnn.cu:288-304 */
     ~qvrcnn();
 
     int layers;

@@ -25,7 +25,7 @@ SYMBOLS = (
     # dynamic-quantisation path
     "qcnn_load_para", "qcnn_load_para_mem", "qcnn_forward", "qcnn_dynamic_state", "qcnn_op_activate",
     "qcnn_op_find_max", "qcnn_op_quant_div", "qcnn_op_mul_shift", "qcnn_op_adjust_basic", "qcnn_op_adjust_output",
-    "qcnn_op_adjust_output_static", "qcnn_op_apply_res", "qcnn_concat_steps",
+    "qcnn_op_adjust_output_static", "qcnn_op_apply_res", "qcnn_concat_steps", "qcnn_layer_b_adj_device_ptr",
 )
 
 TAP_X_PPRO, TAP_U_C1, TAP_U_C2_1, TAP_U_C2_2, TAP_U_C3_1, TAP_U_C3_2, TAP_U_C4 = range(7)
@@ -122,6 +122,8 @@ def load():
     L.qcnn_op_adjust_output.argtypes = [vp, vp, vp, vp, i, sz, vp]
     L.qcnn_op_adjust_output_static.argtypes = [vp, vp, i, i, sz, vp]
     L.qcnn_op_apply_res.argtypes = [vp, vp, vp, sz, vp]
+    L.qcnn_layer_b_adj_device_ptr.restype = vp
+    L.qcnn_layer_b_adj_device_ptr.argtypes = [vp, i]
     L.qcnn_concat_steps.argtypes = [C.c_float, C.c_float, i, i, C.POINTER(i), C.POINTER(i)]
     _lib = L
     return L

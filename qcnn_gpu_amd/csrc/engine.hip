@@ -309,8 +309,6 @@ static int load_dyn_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
         p += 4 * L_COUT[l];
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (!e->dyn) HIP_TRY(hipMalloc(&e->dyn, sizeof(DynState)));
-    if (!e->v4) HIP_TRY(hipMalloc(&e->v4, e->HW));
     HIP_TRY(hipMemcpy(e->dyn, &st, sizeof(DynState), hipMemcpyHostToDevice));
     for (int l = 0; l < 6; ++l) HIP_TRY(hipMemcpy(e->w_file[l], wptr[l], wsize(l), hipMemcpyHostToDevice));
     e->dyn_loaded = true;
@@ -418,6 +416,9 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY_E(hipMalloc(&e->bias_i, 161 * sizeof(int)));
     HIP_TRY_E(hipMalloc(&e->bias_f, 161 * sizeof(float)));
     HIP_TRY_E(hipMalloc(&e->sse_dev, sizeof(unsigned long long)));
+    HIP_TRY_E(hipMalloc(&e->dyn, sizeof(DynState)));
+    HIP_TRY_E(hipMemset(e->dyn, 0, sizeof(DynState)));
+    HIP_TRY_E(hipMalloc(&e->v4, e->HW));
 #ifdef QCNN_STAMPS
     HIP_TRY_E(hipMalloc(&e->dbg, 24 * 128 * sizeof(unsigned long long)));
     HIP_TRY_E(hipMemset(e->dbg, 0, 24 * 128 * sizeof(unsigned long long)));
@@ -878,9 +879,7 @@ static int tap_info(qcnn_t *e, int tap, void **dev, size_t *bytes)
     case QCNN_TAP_CONC2: *dev = e->conc2; *bytes = 48 * HW; return 0;
     case QCNN_TAP_X_REC: *dev = e->bound_rec ? e->bound_rec : e->x_rec; *bytes = HW; return 0;
     case QCNN_TAP_FUSED_CONC1: *dev = e->conc1_int; *bytes = 48 * HW; return 0;
-    case QCNN_TAP_V_C4:
-        if (!e->v4) return fail(QCNN_E_STATE, "C4.v exists only after load_para");
-        *dev = e->v4; *bytes = HW; return 0;
+    case QCNN_TAP_V_C4: *dev = e->v4; *bytes = HW; return 0;
     default: return fail(QCNN_E_ARG, "unknown tap %d", tap);
     }
 }
@@ -895,7 +894,7 @@ int qcnn_tap_bytes(qcnn_t *e, int tap, size_t *bytes)
 void *qcnn_tap_device_ptr(qcnn_t *e, int tap)
 {
     if (!e) return nullptr;
-    if (tap != QCNN_TAP_X_REC && tap != QCNN_TAP_FUSED_CONC1 && ensure_layered(e)) return nullptr;
+    if (tap != QCNN_TAP_X_REC && tap != QCNN_TAP_FUSED_CONC1 && tap != QCNN_TAP_V_C4 && ensure_layered(e)) return nullptr;
     void *dev = nullptr;
     size_t bytes;
     if (tap_info(e, tap, &dev, &bytes)) return nullptr;
@@ -944,7 +943,12 @@ int qcnn_layer_params(qcnn_t *e, int layer, int *blu, int *mul, int *shift)
 void *qcnn_layer_w_device_ptr(qcnn_t *e, int layer) { return (e && layer >= 0 && layer < 6) ? e->w_file[layer] : nullptr; }
 void *qcnn_layer_b_device_ptr(qcnn_t *e, int layer)
 {
-    return (e && layer >= 0 && layer < 6) ? (void *)(e->bias_f + BIAS_OFF[layer]) : nullptr;
+    if (!e || layer < 0 || layer >= 6) return nullptr;
+    return e->dyn_loaded ? (void *)(e->dyn->b + BIAS_OFF[layer]) : (void *)(e->bias_f + BIAS_OFF[layer]);
+}
+void *qcnn_layer_b_adj_device_ptr(qcnn_t *e, int layer)
+{
+    return (e && layer >= 0 && layer < 6) ? (void *)(e->dyn->b_adj + BIAS_OFF[layer]) : nullptr;
 }
 
 int qcnn_set_timing(qcnn_t *e, int on)

@@ -5,7 +5,7 @@
 
 static int unsupported(const char *what)
 {
-    printf("%s: only the static-quantised (blu) path is implemented\n", what);
+    printf("%s: not available in this configuration\n", what);
     return QCNN_E_UNSUPPORTED;
 }
 static inline int pad4(int c) { return (c + 3) / 4 * 4; }
@@ -136,16 +136,67 @@ int CovLayer::viewmem(xwtype *x)
     return 0;
 }
 
-int CovLayer::load_para(FILE *) { check(unsupported("CovLayer::load_para")); return 0; }
-int CovLayer::ConvForward(qcnnHandle_t, qcnnTensorDescriptor_t, void *, void *, size_t)
+int CovLayer::load_para(FILE *fp)
 {
-    check(unsupported("CovLayer::ConvForward"));
+    xwtype *w_h = (xwtype *)malloc(sizeof(xwtype) * (size_t)wSize);
+    btype *b_h = (btype *)malloc(sizeof(btype) * (size_t)outChannel);
+    int *b_int = (int *)malloc(sizeof(int) * (size_t)outChannel);
+    size_t ok = fread(&step_w, sizeof(int), 1, fp) == 1;
+    ok &= fread(w_h, sizeof(xwtype), (size_t)wSize, fp) == (size_t)wSize;
+    ok &= fread(b_int, sizeof(int), (size_t)outChannel, fp) == (size_t)outChannel;
+    if (!ok) {
+        printf("model file is too short.\n");
+        exit(1);
+    }
+    for (int i = 0; i < outChannel; i++) b_h[i] = (btype)b_int[i];  // inference/cnn.cu:81
+    if (owns_) {  // adopted layers get their parameters through the engine's own loader
+        check(qcnn_dev_h2d(w, w_h, sizeof(xwtype) * (size_t)wSize));
+        check(qcnn_dev_h2d(b, b_h, sizeof(btype) * (size_t)outChannel));
+    }
+    free(w_h);
+    free(b_h);
+    free(b_int);
     return 0;
 }
-int CovLayer::activate(qcnnHandle_t) { check(unsupported("CovLayer::activate")); return 0; }
-int CovLayer::quantize_out(void *) { check(unsupported("CovLayer::quantize_out")); return 0; }
-int CovLayer::quantize_out_fix(int) { check(unsupported("CovLayer::quantize_out_fix")); return 0; }
-int CovLayer::quantize_out_static(void) { check(unsupported("CovLayer::quantize_out_static")); return 0; }
+
+int CovLayer::ConvForward(qcnnHandle_t handle, qcnnTensorDescriptor_t, void *x, void *, size_t)
+{
+    // convolution + cudnnAddTensor of b_adj (inference/cnn.cu:132-139)
+    check(qcnn_op_conv_static(x, w, b_adj, u, height, width, inChannel, outChannel, ksize,
+                              handle ? handle->stream : nullptr));
+    return 0;
+}
+
+int CovLayer::activate(qcnnHandle_t handle)
+{
+    check(qcnn_op_activate(u, (size_t)uSize, handle ? handle->stream : nullptr));
+    return 0;
+}
+
+int CovLayer::quantize_out(void *workspace)
+{
+    convtype max;
+    findMax((convtype *)u, (convtype *)workspace, uSize, &max);
+    max_u = max;
+    step_y = max / (THRESHOLD + 1) + 1;
+    NCHW2NCHW_VECT_C((convtype *)u, (xwtype *)v, step_y, batch, outChannel, height, width);
+    return 0;
+}
+
+int CovLayer::quantize_out_fix(int max_u_)
+{
+    convtype max = max_u_;
+    max_u = max_u_;
+    step_y = max / (THRESHOLD + 1) + 1;
+    NCHW2NCHW_VECT_C((convtype *)u, (xwtype *)v, step_y, batch, outChannel, height, width);
+    return 0;
+}
+
+int CovLayer::quantize_out_static(void)
+{
+    check(qcnn_op_mul_shift(u, v, (size_t)uSize, mul, shift, nullptr));
+    return 0;
+}
 
 CovLayer::~CovLayer()
 {
@@ -205,7 +256,31 @@ int ConcatLayer::concat_blu(CovLayer *C1, CovLayer *C2)
     return 0;
 }
 
-int ConcatLayer::concat(CovLayer *, CovLayer *, void *) { check(unsupported("ConcatLayer::concat")); return 0; }
+int ConcatLayer::concat(CovLayer *C1, CovLayer *C2, void *workspace)
+{
+    convtype max1, max2;
+    findMax((convtype *)C1->u, (convtype *)workspace, C1->uSize, &max1);
+    findMax((convtype *)C2->u, (convtype *)workspace, C2->uSize, &max2);
+    return concat_fix(C1, C2, max1, max2);
+}
+
+int ConcatLayer::concat_fix(CovLayer *C1, CovLayer *C2, convtype max1, convtype max2)
+{
+    int stepy1, stepy2;
+    C1->max_u = max1;
+    C2->max_u = max2;
+    check(qcnn_concat_steps(max1, max2, C1->step_w, C2->step_w, &stepy1, &stepy2));  // inference/cnn.cu:295-307
+    C1->step_y = stepy1;
+    C2->step_y = stepy2;
+    const size_t hw = (size_t)height * width;
+    for (int i = 0; i < batch; i++) {
+        check(qcnn_op_quant_div((convtype *)C1->u + i * inChannel1 * hw, (xwtype *)conc + i * outChannel * hw, hw,
+                                inChannel1, stepy1, nullptr));
+        check(qcnn_op_quant_div((convtype *)C2->u + i * inChannel2 * hw,
+                                (xwtype *)conc + i * outChannel * hw + inChannel1 * hw, hw, inChannel2, stepy2, nullptr));
+    }
+    return 0;
+}
 
 ConcatLayer::~ConcatLayer()
 {
@@ -270,7 +345,11 @@ int InputLayer::applyRes_y(convtype *res, int mul, int shift)
     return 0;
 }
 
-int InputLayer::applyRes(xwtype *) { check(unsupported("InputLayer::applyRes")); return 0; }
+int InputLayer::applyRes(xwtype *res)
+{
+    check(qcnn_op_apply_res(x, res, x_rec, (size_t)inSize, nullptr));
+    return 0;
+}
 
 InputLayer::~InputLayer(void)
 {
@@ -297,5 +376,18 @@ int NCHW2NCHW_VECT_C_QUANT_BLU(convtype *before, xwtype *after, int N, int C, in
     for (int i = 0; i < N; i++)
         check(qcnn_op_quant_blu(before + i * frameSize, after + i * frameSize, (size_t)H * W, C, blu, multiplier, shifts,
                                 nullptr));
+    return 0;
+}
+
+void findMax(convtype *data, convtype *buffer, int n, convtype *max)
+{
+    check(qcnn_op_find_max(data, buffer, (size_t)n, max, nullptr));
+}
+
+int NCHW2NCHW_VECT_C(convtype *dividend, xwtype *quotient, int divisor, int N, int C, int H, int W)
+{
+    const size_t frameSize = (size_t)C * H * W;
+    for (int i = 0; i < N; i++)
+        check(qcnn_op_quant_div(dividend + i * frameSize, quotient + i * frameSize, (size_t)H * W, C, divisor, nullptr));
     return 0;
 }

@@ -4,6 +4,11 @@
 //   <out>.fused   x_rec of qvrcnn::forward_blu           (fused kernels)
 //   <out>.layers  x_rec of qvrcnn::forward_blu_layers    (layer objects, reference call order)
 //   <out>.c1v     C1.v of a stand-alone InputLayer + CovLayer pair that own their buffers
+// and, when a dynamic-quantisation model is given as 7th argument (inference/qvrcnn.cu:82-167):
+//   <out>.dyn         x_rec of qvrcnn::forward           (one asynchronous kernel sequence)
+//   <out>.dynlayers   x_rec of qvrcnn::forward_layers    (layer objects, host round trips)
+//   <out>.b_adj       the file qvrcnn::save_b_adj appends
+//   <out>.c1dyn       C1.v of a stand-alone CovLayer through load_para / ConvForward / quantize_out
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
@@ -57,6 +62,42 @@ int main(int argc, char **argv)
     C1.quantize_out_blu();
     dump(out + ".c1v", C1.v, (size_t)64 * H * W);
     if (getenv("FACADE_VIEWMEM")) C1.viewmem((xwtype *)I1.x_ppro);
+
+    if (argc > 7) {
+        char *dmodel = argv[7];
+        net.load_para(dmodel);
+        net.load_data(d.input);
+        net.forward();
+        dump(out + ".dyn", net.I1.x_rec, (size_t)H * W);
+        printf("dyn steps w %d %d %d %d y %d %d %d %d\n", net.steps.stepw[0], net.steps.stepw[1], net.steps.stepw[2],
+               net.steps.stepw[3], net.steps.stepy[0], net.steps.stepy[1], net.steps.stepy[2], net.steps.stepy[3]);
+        printf("dyn step_y %d %d %d %d %d max_u %d %d\n", net.C1.step_y, net.C2_1.step_y, net.C2_2.step_y, net.C3_1.step_y,
+               net.C3_2.step_y, net.C1.max_u, net.C3_2.max_u);
+        remove((out + ".b_adj").c_str());
+        net.save_b_adj((out + ".b_adj").c_str());
+        check(qcnn_dev_memset(net.I1.x_rec, 0, (size_t)H * W));
+        for (int k = 0; k < LAYER; ++k) net.steps.stepw[k] = net.steps.stepy[k] = 0;
+        net.forward_layers();
+        dump(out + ".dynlayers", net.I1.x_rec, (size_t)H * W);
+        printf("layers steps w %d %d %d %d y %d %d %d %d\n", net.steps.stepw[0], net.steps.stepw[1], net.steps.stepw[2],
+               net.steps.stepw[3], net.steps.stepy[0], net.steps.stepy[1], net.steps.stepy[2], net.steps.stepy[3]);
+
+        // stand-alone dynamic layer: load_para, ConvForward with b_adj, quantize_out
+        CovLayer D1;
+        D1.build(&hs, I1.xDesc, 1, H, W, CHANNEL, 64, 5);
+        fp = fopen(dmodel, "rb");
+        D1.load_para(fp);
+        fclose(fp);
+        step_parameters none = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        adjustBasic(none, (btype *)D1.b, (btype *)D1.b_adj, D1.outChannel, 0);
+        void *ws = nullptr;
+        check(qcnn_dev_alloc(&ws, 256));
+        D1.ConvForward(&hs, I1.xDesc, I1.x_ppro, ws, 256);
+        D1.quantize_out(ws);
+        dump(out + ".c1dyn", D1.v, (size_t)64 * H * W);
+        printf("standalone step_w %d step_y %d max_u %d\n", D1.step_w, D1.step_y, D1.max_u);
+        check(qcnn_dev_free(ws));
+    }
     printf("psnr before %.6f after %.6f\n", d.psnr(d.input), 0.0);
     return 0;
 }

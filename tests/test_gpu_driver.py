@@ -147,3 +147,29 @@ def test_cpp_layer_api_matches_oracle(tmp_path):
     t = synth.QUANT_TRIPLES[qp]
     assert f"C1 blu={t[0][0]} mul={t[0][1]} shift={t[0][2]}  C4 mul={t[5][1]} shift={t[5][2]}" in r.stdout
     assert "mul:%d,shift:%d" % (t[0][1], t[0][2]) in r.stdout      # viewmem dump, inference/cnn.cu:235
+
+
+def test_cpp_dynamic_layer_api_matches_oracle(tmp_path):
+    """The dynamic-quantisation members of the C++ classes (qvrcnn::load_para / forward / save_b_adj,
+    CovLayer::load_para / ConvForward / activate / quantize_out, ConcatLayer::concat, adjustBasic /
+    adjustOutput, InputLayer::applyRes) against the oracle of inference/qvrcnn.cu:82-167."""
+    h, w, qp = 50, 70, 27
+    _write_case(tmp_path, h, w, [qp])
+    dm = synth.synth_dynamic_model(qp)
+    (tmp_path / "dyn.data").write_bytes(dm.to_bytes())
+    out = tmp_path / "out"
+    r = subprocess.run([FACADE, str(tmp_path / f"model_{qp}.data"), str(tmp_path / "seq.yuv"),
+                        str(tmp_path / f"anchor_Q{qp}.yuv"), str(h), str(w), str(out), str(tmp_path / "dyn.data")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    anc = formats.read_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), 1, h, w)
+    rec_o, t = c_oracle.forward_dynamic(dm.to_bytes(), anc[0], True)
+    assert np.array_equal(np.fromfile(str(out) + ".dyn", np.uint8).reshape(h, w), rec_o)
+    assert np.array_equal(np.fromfile(str(out) + ".dynlayers", np.uint8).reshape(h, w), rec_o)
+    assert np.array_equal(np.fromfile(str(out) + ".c1dyn", np.int8).reshape(16, h, w, 4), t["v1"])
+    assert np.array_equal(np.fromfile(str(out) + ".b_adj", np.float32), t["b_adj"])
+    steps = "w %d %d %d %d y %d %d %d %d" % (*t["stepw"], *t["stepy"])
+    assert "dyn steps " + steps in r.stdout and "layers steps " + steps in r.stdout
+    sy, mu = t["step_y"], t["max_u"]
+    assert "dyn step_y %d %d %d %d %d max_u %d %d" % (sy[0], sy[1], sy[2], sy[3], sy[4], mu[0], mu[4]) in r.stdout
+    assert "standalone step_w %d step_y %d max_u %d" % (dm.layers[0].step_w, sy[0], mu[0]) in r.stdout
