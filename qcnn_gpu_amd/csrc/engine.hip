@@ -769,31 +769,37 @@ int qcnn_forward(qcnn_t *e)
     uint8_t *rec = e->bound_rec ? e->bound_rec : e->x_rec;
     DynState *st = e->dyn;
     const float *badj = st->b_adj;  // device addresses; never dereferenced on the host
+    // convolution + bias (+ ReLU) with the layer's largest |u| collected on the way: fused into the
+    // matrix-core kernel's epilogue, or a separate reduction behind the direct kernel
+    auto conv = [&](const void *x, int l, int relu) -> hipError_t {
+        const float *b = badj + BIAS_OFF[l];
+        if (!conv_direct_only() && conv_mfma_supported(L_CIN[l], L_COUT[l], L_KS[l]))
+            return launch_conv_mfma(x, e->w_file[l], b, e->u[l], nullptr, l < 5 ? &st->maxbits[l] : nullptr, nullptr, 1,
+                                    relu, H, W, L_CIN[l], L_COUT[l], L_KS[l], s);
+        hipError_t he = launch_conv_static(x, e->w_file[l], b, e->u[l], H, W, L_CIN[l], L_COUT[l], L_KS[l], relu, s);
+        if (he == hipSuccess && l < 5) he = launch_absmax(e->u[l], (size_t)L_COUT[l] * HW, &st->maxbits[l], s);
+        return he;
+    };
     HIP_TRY(launch_dyn_book(st, 0, s));
     HIP_TRY(launch_ppro(y, e->x_ppro, HW, s));
     // layer 1: no activation (inference/qvrcnn.cu:96 is commented out)
-    HIP_TRY(launch_conv_static(e->x_ppro, e->w_file[0], badj + BIAS_OFF[0], e->u[0], H, W, 1, 64, 5, 0, s));
-    HIP_TRY(launch_absmax(e->u[0], 64 * HW, &st->maxbits[0], s));
+    HIP_TRY(conv(e->x_ppro, 0, 0));
     HIP_TRY(launch_dyn_book(st, 1, s));
     HIP_TRY(launch_quant_div(e->u[0], e->v1, HW, 64, 0, &st->step_y[0], s));
     // layer 2
-    HIP_TRY(launch_conv_static(e->v1, e->w_file[1], badj + BIAS_OFF[1], e->u[1], H, W, 64, 32, 3, 1, s));
-    HIP_TRY(launch_conv_static(e->v1, e->w_file[2], badj + BIAS_OFF[2], e->u[2], H, W, 64, 16, 5, 1, s));
-    HIP_TRY(launch_absmax(e->u[1], 32 * HW, &st->maxbits[1], s));
-    HIP_TRY(launch_absmax(e->u[2], 16 * HW, &st->maxbits[2], s));
+    HIP_TRY(conv(e->v1, 1, 1));
+    HIP_TRY(conv(e->v1, 2, 1));
     HIP_TRY(launch_dyn_book(st, 2, s));
     HIP_TRY(launch_quant_div(e->u[1], e->conc1, HW, 32, 0, &st->step_y[1], s));
     HIP_TRY(launch_quant_div(e->u[2], e->conc1 + 32 * HW, HW, 16, 0, &st->step_y[2], s));
     // layer 3
-    HIP_TRY(launch_conv_static(e->conc1, e->w_file[3], badj + BIAS_OFF[3], e->u[3], H, W, 48, 16, 3, 1, s));
-    HIP_TRY(launch_conv_static(e->conc1, e->w_file[4], badj + BIAS_OFF[4], e->u[4], H, W, 48, 32, 1, 1, s));
-    HIP_TRY(launch_absmax(e->u[3], 16 * HW, &st->maxbits[3], s));
-    HIP_TRY(launch_absmax(e->u[4], 32 * HW, &st->maxbits[4], s));
+    HIP_TRY(conv(e->conc1, 3, 1));
+    HIP_TRY(conv(e->conc1, 4, 1));
     HIP_TRY(launch_dyn_book(st, 3, s));
     HIP_TRY(launch_quant_div(e->u[3], e->conc2, HW, 16, 0, &st->step_y[3], s));
     HIP_TRY(launch_quant_div(e->u[4], e->conc2 + 16 * HW, HW, 32, 0, &st->step_y[4], s));
     // layer 4 and restore
-    HIP_TRY(launch_conv_static(e->conc2, e->w_file[5], badj + BIAS_OFF[5], e->u[5], H, W, 48, 1, 3, 0, s));
+    HIP_TRY(conv(e->conc2, 5, 0));
     HIP_TRY(launch_dyn_book(st, 4, s));
     HIP_TRY(launch_adjust_output(DynSteps(), &st->steps, e->u[5], e->v4, 4, HW, s));
     HIP_TRY(launch_apply_res(y, e->v4, rec, HW, s));

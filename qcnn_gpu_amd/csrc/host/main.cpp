@@ -48,15 +48,22 @@ static std::vector<int> parse_qps(const char *s)
     return out;
 }
 
+// QCNN_DYNAMIC=1 runs the dynamic-quantisation pass instead (the commented-out alternative of the
+// reference's driver, inference/kernel.cu:87,93: load_para + forward); the model file is then the
+// dynamic format (step_w + weights + biases per layer).
+static bool dynamic_mode() { return getenv("QCNN_DYNAMIC") != nullptr; }
+static void load_model(qvrcnn &net, char *model_fn) { dynamic_mode() ? net.load_para(model_fn) : net.load_static_para(model_fn); }
+static void run_frame(qvrcnn &net) { dynamic_mode() ? net.forward() : net.forward_blu(); }
+
 // One worker per GPU: the frame loop of inference/kernel.cu:91-97 over frames g, g+G, g+2G, ...
 static void worker(int gpu, int ngpu, char *model_fn, vrcnn_data *d, int frame, int channel, int height, int width)
 {
     qvrcnn net(gpu, 1, channel, height, width);
-    net.load_static_para(model_fn);
+    load_model(net, model_fn);
     const long fs = (long)channel * height * width;
     for (int i = gpu; i < frame; i += ngpu) {
         net.load_data(d->input + i * fs);
-        net.forward_blu();
+        run_frame(net);
         check(qcnn_sync(net.engine));
         check(qcnn_dev_d2h(d->recon + i * fs, net.I1.x_rec, (size_t)fs));
     }
@@ -127,7 +134,7 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
 {
     vrcnn_data test_data(frame, height, width);
     long long us;
-    if (getenv("QCNN_PIPELINE")) {
+    if (getenv("QCNN_PIPELINE") && !dynamic_mode()) {
         // engines and models are set up before the clock starts (inference/kernel.cu:86-90); the timed
         // region is the pipelined frame loop on every GPU, frames sharded round-robin
         if (ngpu < 1) ngpu = 1;
@@ -160,13 +167,13 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
             ch = height;
             cw = width;
         }
-        cached->load_static_para(model_fn);
+        load_model(*cached, model_fn);
         test_data.read_data(ori_fn, input_fn);
         const long fs = (long)channel * height * width;
         const auto t1 = std::chrono::steady_clock::now();
         for (int i = 0; i < frame; i++) {
             cached->load_data(test_data.input + i * fs);
-            cached->forward_blu();
+            run_frame(*cached);
             check(qcnn_sync(cached->engine));
             check(qcnn_dev_d2h(test_data.recon + i * fs, cached->I1.x_rec, (size_t)fs));
         }

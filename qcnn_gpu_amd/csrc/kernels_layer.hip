@@ -2,6 +2,7 @@
 // reference's own buffer layouts.  They back the qcnn_op_* entry points and the layered (tap)
 // mode; the production pass is the pair of fused kernels in kernels_fused.hip.
 #include "qcnn_internal.h"
+#include <stdlib.h>
 
 namespace qcnn {
 
@@ -96,9 +97,21 @@ static hipError_t conv_dispatch(const void *x, const void *w, const void *b, voi
     return hipGetLastError();
 }
 
+// QCNN_CONV_DIRECT=1 keeps every layer-level convolution on the direct v_dot4 kernel (A/B timing, tests).
+bool conv_direct_only()
+{
+    static const bool v = [] {
+        const char *e = getenv("QCNN_CONV_DIRECT");
+        return e && atoi(e) != 0;
+    }();
+    return v;
+}
+
 hipError_t launch_conv_static(const void *x, const void *w, const void *b, void *u, int H, int W, int cin,
                               int cout, int ks, int relu, hipStream_t s)
 {
+    if (!conv_direct_only() && conv_mfma_supported(cin, cout, ks))
+        return launch_conv_mfma(x, w, b, u, nullptr, nullptr, nullptr, 1, relu, H, W, cin, cout, ks, s);
     switch (ks) {
     case 1: return conv_dispatch<1>(x, w, b, u, H, W, cin, cout, relu, s);
     case 3: return conv_dispatch<3>(x, w, b, u, H, W, cin, cout, relu, s);

@@ -138,6 +138,13 @@ hipError_t launch_ppro(const void *x, void *x_ppro, size_t n, hipStream_t s);
 // relu != 0 applies CovLayer::activate (inference/cnn.cu:161-166) to the result before it is stored
 hipError_t launch_conv_static(const void *x, const void *w, const void *b, void *u, int H, int W, int cin,
                               int cout, int ks, int relu, hipStream_t s);
+// The same convolution on the matrix cores (kernels_conv_mfma.hip) for the layer shapes of the network,
+// with optional fused passes: u (float NCHW), q (divide-quantised int8 NCHW_VECT_C), maxbits (largest |u|).
+bool conv_mfma_supported(int cin, int cout, int ks);
+bool conv_direct_only();  // QCNN_CONV_DIRECT=1: keep the layer-level convolutions on the v_dot4 kernel
+hipError_t launch_conv_mfma(const void *x, const void *w, const void *b, void *u, void *q, unsigned *maxbits,
+                            const int *divisor_dev, int divisor, int relu, int H, int W, int cin, int cout, int ks,
+                            hipStream_t s);
 hipError_t launch_absmax(const void *u, size_t n, unsigned *maxbits, hipStream_t s);
 hipError_t launch_relu(void *u, size_t n, hipStream_t s);
 hipError_t launch_quant_div(const void *u, void *out, size_t hw, int channels, int divisor, const int *divisor_dev,

@@ -173,3 +173,22 @@ def test_cpp_dynamic_layer_api_matches_oracle(tmp_path):
     sy, mu = t["step_y"], t["max_u"]
     assert "dyn step_y %d %d %d %d %d max_u %d %d" % (sy[0], sy[1], sy[2], sy[3], sy[4], mu[0], mu[4]) in r.stdout
     assert "standalone step_w %d step_y %d max_u %d" % (dm.layers[0].step_w, sy[0], mu[0]) in r.stdout
+
+
+def test_driver_dynamic_mode(tmp_path):
+    """QCNN_DYNAMIC=1: the driver's other mode (inference/kernel.cu:87,93 commented alternative,
+    load_para + forward) over a 3-frame clip; PSNR equals the oracle's to the last printed decimal."""
+    h, w, qp, frames = 64, 96, 32, 3
+    ori, anc = synth.synth_frames(h, w, qp, frames=frames)
+    formats.write_yuv420_luma(str(tmp_path / "seq.yuv"), ori)
+    formats.write_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), anc)
+    dm = synth.synth_dynamic_model(qp).to_bytes()
+    (tmp_path / f"model_{qp}.data").write_bytes(dm)
+    r = _run(tmp_path, h, w, {"QCNN_QPS": str(qp), "QCNN_FRAMES": str(frames), "QCNN_DYNAMIC": "1",
+                              "QCNN_SAVE_RECON": "recon.yuv"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    rec_o = np.stack([c_oracle.forward_dynamic(dm, a) for a in anc])
+    m = re.search(r"\nbefore net:PSNR=([\d.]+)\nafter quantized net:PSNR=([\d.]+)\ntime:(\d+)us\n", r.stdout)
+    assert m, r.stdout
+    assert m.group(1) == "%.3f" % c_oracle.psnr(anc, ori) and m.group(2) == "%.3f" % c_oracle.psnr(rec_o, ori)
+    assert np.array_equal(formats.read_yuv420_luma(str(tmp_path / "recon.yuv"), frames, h, w), rec_o)
