@@ -115,8 +115,15 @@ int qcnn_load_para_mem(qcnn_t *e, const void *image, size_t bytes);
  * adjustOutput(steps, ..) (:156) -- and everything else as written: adjustBasic before every
  * convolution, no activation after C1, ReLU after C2_x / C3_x, insert_w / insert_y, applyRes.
  * save_steps (:163) is a debug file append and is left to the caller.  Asynchronous on the engine
- * stream: the step bookkeeping runs on the device, no maximum travels to the host. */
+ * stream: the step bookkeeping runs on the device, no maximum travels to the host.  No float32 image
+ * is written: each layer's convolution runs once for its largest |u| and once more with the
+ * divide-quantiser in its epilogue (C1.v, Conc1.conc, Conc2.conc, C4.u, C4.v and I1.x_rec are
+ * materialised; C1.u .. C3_2.u are not). */
 int qcnn_forward(qcnn_t *e);
+
+/* The same pass with every u written as float32 NCHW, as the reference does (tap / debug mode: all the
+ * QCNN_TAP_* buffers are valid afterwards).  Results are identical to qcnn_forward. */
+int qcnn_forward_layered(qcnn_t *e);
 
 /* Host copy of what the reference keeps in qvrcnn::steps and CovLayer::step_w / step_y / max_u / b_adj
  * after forward() (synchronises the engine stream). */

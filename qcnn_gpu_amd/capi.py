@@ -23,7 +23,7 @@ SYMBOLS = (
     "qcnn_dev_d2h", "qcnn_dev_memset", "qcnn_dev_sync", "qcnn_host_alloc_pinned", "qcnn_host_free_pinned",
     "qcnn_hwcn2nchw_vect_c", "qcnn_model_qfp_hwcn2nchw_vect_c",
     # dynamic-quantisation path
-    "qcnn_load_para", "qcnn_load_para_mem", "qcnn_forward", "qcnn_dynamic_state", "qcnn_op_activate",
+    "qcnn_load_para", "qcnn_load_para_mem", "qcnn_forward", "qcnn_forward_layered", "qcnn_dynamic_state", "qcnn_op_activate",
     "qcnn_op_find_max", "qcnn_op_quant_div", "qcnn_op_mul_shift", "qcnn_op_adjust_basic", "qcnn_op_adjust_output",
     "qcnn_op_adjust_output_static", "qcnn_op_apply_res", "qcnn_concat_steps", "qcnn_layer_b_adj_device_ptr",
 )
@@ -113,6 +113,7 @@ def load():
     L.qcnn_load_para.argtypes = [vp, C.c_char_p]
     L.qcnn_load_para_mem.argtypes = [vp, vp, sz]
     L.qcnn_forward.argtypes = [vp]
+    L.qcnn_forward_layered.argtypes = [vp]
     L.qcnn_dynamic_state.argtypes = [vp, C.POINTER(DynamicState)]
     L.qcnn_op_activate.argtypes = [vp, sz, vp]
     L.qcnn_op_find_max.argtypes = [vp, vp, sz, C.POINTER(C.c_float), vp]

@@ -755,7 +755,15 @@ int qcnn_load_para(qcnn_t *e, const char *path)
 // qvrcnn::forward (inference/qvrcnn.cu:82-167) with quantize_out / concat / adjustOutput in the places
 // where the shipped text calls their static counterparts (see include/qcnn.h).  The host bookkeeping
 // between the layers runs on the device (k_dyn_book), so nothing here waits for the GPU.
-int qcnn_forward(qcnn_t *e)
+//
+// taps = true : every u is written as float32 NCHW, as the reference does; the largest |u| is collected
+//               in the convolution's epilogue and a separate kernel divides and relayouts (tap mode).
+// taps = false: no float image exists.  Every layer's convolution runs twice on the matrix cores: once
+//               keeping only the largest |u|, and, after the bookkeeping kernel has turned it into a step,
+//               once more with the divide-quantiser in the epilogue, writing int8 directly.  The pass then
+//               moves 1 + 64 + 48 + 48 + 4 + 1 + 1 bytes per pixel instead of the 644 B/px of float images
+//               written and read twice.
+static int forward_dynamic(qcnn_engine *e, bool taps)
 {
     if (!e) return fail(QCNN_E_ARG, "null engine");
     if (!e->dyn_loaded) return fail(QCNN_E_STATE, "forward before load_para");
@@ -769,42 +777,53 @@ int qcnn_forward(qcnn_t *e)
     uint8_t *rec = e->bound_rec ? e->bound_rec : e->x_rec;
     DynState *st = e->dyn;
     const float *badj = st->b_adj;  // device addresses; never dereferenced on the host
-    // convolution + bias (+ ReLU) with the layer's largest |u| collected on the way: fused into the
-    // matrix-core kernel's epilogue, or a separate reduction behind the direct kernel
-    auto conv = [&](const void *x, int l, int relu) -> hipError_t {
+    const bool mfma = !conv_direct_only();
+    if (!taps && !mfma) taps = true;  // the recomputing pass exists on the matrix-core kernel only
+    // convolution + bias (+ ReLU) of layer l; q != null: quantised output only, else float u (taps) or
+    // nothing but the maximum
+    auto conv = [&](const void *x, int l, int relu, bool want_u, void *q) -> hipError_t {
         const float *b = badj + BIAS_OFF[l];
-        if (!conv_direct_only() && conv_mfma_supported(L_CIN[l], L_COUT[l], L_KS[l]))
-            return launch_conv_mfma(x, e->w_file[l], b, e->u[l], nullptr, l < 5 ? &st->maxbits[l] : nullptr, nullptr, 1,
-                                    relu, H, W, L_CIN[l], L_COUT[l], L_KS[l], s);
+        unsigned *mx = (l < 5 && !q) ? &st->maxbits[l] : nullptr;
+        if (mfma && conv_mfma_supported(L_CIN[l], L_COUT[l], L_KS[l]))
+            return launch_conv_mfma(x, e->w_file[l], b, want_u ? e->u[l] : nullptr, q, mx, q ? &st->step_y[l] : nullptr,
+                                    1, relu, H, W, L_CIN[l], L_COUT[l], L_KS[l], s);
         hipError_t he = launch_conv_static(x, e->w_file[l], b, e->u[l], H, W, L_CIN[l], L_COUT[l], L_KS[l], relu, s);
-        if (he == hipSuccess && l < 5) he = launch_absmax(e->u[l], (size_t)L_COUT[l] * HW, &st->maxbits[l], s);
+        if (he == hipSuccess && mx) he = launch_absmax(e->u[l], (size_t)L_COUT[l] * HW, mx, s);
         return he;
+    };
+    // one layer of the trunk: branches a (and c, or -1) read `in`, their quantised outputs are concatenated in `out`
+    auto layer = [&](const void *in, int a, int c, int relu, int stage, int8_t *out) -> int {
+        HIP_TRY(conv(in, a, relu, taps, nullptr));
+        if (c >= 0) HIP_TRY(conv(in, c, relu, taps, nullptr));
+        HIP_TRY(launch_dyn_book(st, stage, s));
+        int8_t *out_c = out + (size_t)L_COUT[a] * HW;  // legal because outChannel of branch a is a multiple of 4
+        if (taps) {
+            HIP_TRY(launch_quant_div(e->u[a], out, HW, L_COUT[a], 0, &st->step_y[a], s));
+            if (c >= 0) HIP_TRY(launch_quant_div(e->u[c], out_c, HW, L_COUT[c], 0, &st->step_y[c], s));
+        } else {
+            HIP_TRY(conv(in, a, relu, false, out));
+            if (c >= 0) HIP_TRY(conv(in, c, relu, false, out_c));
+        }
+        return QCNN_OK;
     };
     HIP_TRY(launch_dyn_book(st, 0, s));
     HIP_TRY(launch_ppro(y, e->x_ppro, HW, s));
-    // layer 1: no activation (inference/qvrcnn.cu:96 is commented out)
-    HIP_TRY(conv(e->x_ppro, 0, 0));
-    HIP_TRY(launch_dyn_book(st, 1, s));
-    HIP_TRY(launch_quant_div(e->u[0], e->v1, HW, 64, 0, &st->step_y[0], s));
-    // layer 2
-    HIP_TRY(conv(e->v1, 1, 1));
-    HIP_TRY(conv(e->v1, 2, 1));
-    HIP_TRY(launch_dyn_book(st, 2, s));
-    HIP_TRY(launch_quant_div(e->u[1], e->conc1, HW, 32, 0, &st->step_y[1], s));
-    HIP_TRY(launch_quant_div(e->u[2], e->conc1 + 32 * HW, HW, 16, 0, &st->step_y[2], s));
-    // layer 3
-    HIP_TRY(conv(e->conc1, 3, 1));
-    HIP_TRY(conv(e->conc1, 4, 1));
-    HIP_TRY(launch_dyn_book(st, 3, s));
-    HIP_TRY(launch_quant_div(e->u[3], e->conc2, HW, 16, 0, &st->step_y[3], s));
-    HIP_TRY(launch_quant_div(e->u[4], e->conc2 + 16 * HW, HW, 32, 0, &st->step_y[4], s));
+    rc = layer(e->x_ppro, 0, -1, 0, 1, e->v1);  // layer 1: no activation (inference/qvrcnn.cu:96 is commented out)
+    if (rc) return rc;
+    rc = layer(e->v1, 1, 2, 1, 2, e->conc1);
+    if (rc) return rc;
+    rc = layer(e->conc1, 3, 4, 1, 3, e->conc2);
+    if (rc) return rc;
     // layer 4 and restore
-    HIP_TRY(conv(e->conc2, 5, 0));
+    HIP_TRY(conv(e->conc2, 5, 0, true, nullptr));
     HIP_TRY(launch_dyn_book(st, 4, s));
     HIP_TRY(launch_adjust_output(DynSteps(), &st->steps, e->u[5], e->v4, 4, HW, s));
     HIP_TRY(launch_apply_res(y, e->v4, rec, HW, s));
     return QCNN_OK;
 }
+
+int qcnn_forward(qcnn_t *e) { return forward_dynamic(e, false); }
+int qcnn_forward_layered(qcnn_t *e) { return forward_dynamic(e, true); }
 
 int qcnn_dynamic_state(qcnn_t *e, qcnn_dynamic_state_t *out)
 {

@@ -10,7 +10,7 @@
 // A operand, gathered once per workgroup from the file layout into lane-ordered fragments in LDS;
 // activations are the B operand, read from an LDS tile whose pixels hold their channels contiguously
 // (one 16-byte read per lane and fragment).  Persistent 256-thread workgroups walk 8 x 32 output tiles;
-// wave w owns rows 2w, 2w+1 of the tile (four 16-pixel groups) and all output channels.
+// a wave owns one 16-pixel strip of four rows and all output channels.
 //
 // The single-channel first layer (x_ppro, 4 bytes per pixel with the sample in lane 0) packs four
 // horizontally adjacent taps into one 16-byte k-group: kernel row r is covered by two k-groups
@@ -43,7 +43,8 @@ struct ConvGeom {
     static constexpr int C4 = (CIN + 3) / 4;                     // vec4 groups of the input
     static constexpr int PXB = CIN == 1 ? 4 : CIN == 64 ? 80 : CIN;  // bytes per pixel in the LDS tile
     static constexpr int RH = cm::TH + KS - 1;
-    static constexpr int RW = CIN == 1 ? cm::TW + 8 : cm::TW + KS - 1;
+    static constexpr int RW = CIN == 1 ? cm::TW + 8 : cm::TW + KS - 1;  // region columns held in LDS
+    static constexpr int X0 = P;                                 // the region starts X0 columns left of the tile
     static constexpr int NSTEPS = CIN == 1 ? 3 : KS * KS;        // MFMA K-steps
     static constexpr int SX_BYTES = RH * RW * PXB + 64;          // + slack: k-group 3 of a 48-byte pixel
     static_assert(CIN == 1 || CIN == 48 || CIN == 64, "input channel counts of the VRCNN layers");
@@ -60,7 +61,17 @@ __device__ __forceinline__ int quant_div_val(float t, float half, float d)
     return t > 127.f ? 127 : (int)t;
 }
 
-template <int KS, int CIN, int KT>
+// Workgroup barrier that orders LDS traffic only: global loads (the prefetched tile) and the stores of
+// the epilogue stay in flight across it, which __syncthreads() would wait for.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// VEC (four horizontally adjacent pixels of one vec4 group as one 16-byte load, with the region widened to
+// whole groups) measured slower than dword loads -- 133 against 112 us on the 5x5 64->16 layer at 1080p --
+// and is not instantiated.
+template <int KS, int CIN, int KT, bool VEC>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
 {
     using G = ConvGeom<KS, CIN>;
@@ -115,53 +126,134 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
     const float dvf = (float)divisor, half = (float)(divisor >> 1);
     float amax = 0.f;
 
+    // The input region of a tile travels global -> registers -> LDS; the loads of the next tile are issued
+    // before the MFMAs of the current one, so their latency is covered by compute instead of being paid
+    // once per tile by every wave.  A thread keeps one column group of the region for a fixed set of rows
+    // and vec4 groups, so the addresses of its loads and LDS stores differ by constants only.
+    constexpr int CW = VEC ? 4 : 1;                        // pixels per load
+    constexpr int NCOL = G::RW / CW;                       // loads per region row and vec4 group
+    constexpr int RPP = (256 / NCOL) < G::RH ? (256 / NCOL) : G::RH;  // region rows covered by one pass
+    constexpr int NCHUNK = (G::RH + RPP - 1) / RPP;
+    constexpr int NGRP = (256 / (NCOL * RPP)) < G::C4 ? (256 / (NCOL * RPP)) : G::C4;  // thread groups sharing the vec4 groups
+    constexpr int NC4 = (G::C4 + NGRP - 1) / NGRP;
+    constexpr int NLOAD = NC4 * NCHUNK;
+    const int fgrp = tid / (NCOL * RPP), fin = tid % (NCOL * RPP);
+    const int fcx = fin % NCOL, fry = fin / NCOL;          // fgrp >= NGRP: the thread has no part in the copy
+    const size_t plane = (size_t)H * W;
+    typedef int prevec __attribute__((ext_vector_type(CW)));
+    prevec pre[NLOAD];
+    auto fetch = [&](int tile) {
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int gx = tx * TW + CW * fcx - G::X0;
+        const bool colok = fgrp < NGRP && gx >= 0 && gx < W;  // VEC: gx and W are multiples of 4
+#pragma unroll
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            const int ry = fry + ch * RPP;
+            const int gy = ty * TH + ry - G::P;
+            const bool rowok = colok && ry < G::RH && gy >= 0 && gy < H;
+            const int *src = x32 + ((size_t)gy * W + gx);
+#pragma unroll
+            for (int j = 0; j < NC4; ++j) {
+                const int c4 = fgrp + j * NGRP;
+                prevec v = {};
+#ifndef CM_SKIP_FETCH
+                if (rowok && c4 < G::C4) v = *reinterpret_cast<const prevec *>(src + c4 * plane);
+#endif
+                pre[ch * NC4 + j] = v;
+            }
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
-        __syncthreads();  // the previous tile's readers are done (and the A fragments are complete)
+        lds_barrier();  // the previous tile's readers are done (and the A fragments are complete)
         // ---- input region -> LDS, pixel-major ------------------------------------------------------
-        for (int idx = tid; idx < G::C4 * G::RH * G::RW; idx += 256) {
-            const int rx = idx % G::RW, t2 = idx / G::RW;
-            const int ry = t2 % G::RH, c4 = t2 / G::RH;
-            const int gy = y0 + ry - G::P, gx = x0 + rx - G::P;
-            int v = 0;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x32[((size_t)c4 * H + gy) * W + gx];
-            *reinterpret_cast<int *>(sX + (ry * G::RW + rx) * G::PXB + 4 * c4) = v;
+#pragma unroll
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            const int ry = fry + ch * RPP;
+            if (fgrp < NGRP && ry < G::RH) {
+                unsigned char *dst = sX + (ry * G::RW + CW * fcx) * G::PXB;
+#pragma unroll
+                for (int j = 0; j < NC4; ++j) {
+                    const int c4 = fgrp + j * NGRP;
+                    if (c4 < G::C4) {
+#pragma unroll
+                        for (int px = 0; px < CW; ++px) {
+                            int v;
+                            v = pre[ch * NC4 + j][px];
+                            *reinterpret_cast<int *>(dst + px * G::PXB + 4 * c4) = v;
+                        }
+                    }
+                }
+            }
         }
-        __syncthreads();
+        lds_barrier();
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
         // ---- MFMA ----------------------------------------------------------------------------------------
+        // A wave owns one 16-pixel strip and four rows of the tile.  For one kernel column s it keeps the A
+        // fragments of all kernel rows in registers and walks the 4 + KS - 1 input rows once: the B fragment
+        // of input row yy serves every output row yy - r it contributes to, so a fragment read from LDS
+        // feeds up to KS * KT MFMAs.
+        const int strip = wv & 1, rbase = 4 * (wv >> 1);
         v4i acc[4][KT];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+        for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc[pt][kt] = v4i{0, 0, 0, 0};
+            for (int kt = 0; kt < KT; ++kt) acc[o][kt] = v4i{0, 0, 0, 0};
+        if constexpr (CIN == 1) {
 #pragma unroll
-        for (int step = 0; step < G::NSTEPS; ++step) {
-            v4i af[KT];
+            for (int step = 0; step < G::NSTEPS; ++step) {
+                v4i af[KT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-                af[kt] = *reinterpret_cast<const v4i *>(sA + (size_t)(step * KT + kt) * 1024 + lane * 16);
+                for (int kt = 0; kt < KT; ++kt)
+                    af[kt] = *reinterpret_cast<const v4i *>(sA + (size_t)(step * KT + kt) * 1024 + lane * 16);
+                int gi = 4 * step + g;
+                if (gi >= 10) gi = 0;  // zero weights: any readable address
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                const int row = 2 * wv + (pt >> 1), px = 16 * (pt & 1) + col;
-                v4i bf;
-                if constexpr (CIN == 1) {
-                    int gi = 4 * step + g;
-                    if (gi >= 10) gi = 0;  // zero weights: any readable address
-                    const int *src = reinterpret_cast<const int *>(sX + ((row + (gi >> 1)) * G::RW + px + 4 * (gi & 1)) * 4);
-                    bf = v4i{src[0], src[1], src[2], src[3]};
-                } else {
-                    const int r = step / KS, s = step % KS;
-                    bf = *reinterpret_cast<const v4i *>(sX + ((row + r) * G::RW + px + s) * G::PXB + 16 * g);
+                for (int o = 0; o < 4; ++o) {
+                    const int *src = reinterpret_cast<const int *>(
+                        sX + ((rbase + o + (gi >> 1)) * G::RW + 16 * strip + col + 4 * (gi & 1)) * 4);  // X0 == P: column px + s
+                    const v4i bf = v4i{src[0], src[1], src[2], src[3]};
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[o][kt] = mfma16(af[kt], bf, acc[o][kt]);
                 }
+            }
+        } else {
+#pragma unroll 1
+            for (int sft = 0; sft < KS; ++sft) {
+                v4i af[KS][KT];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) acc[pt][kt] = mfma16(af[kt], bf, acc[pt][kt]);
+                for (int r = 0; r < KS; ++r)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        af[r][kt] = *reinterpret_cast<const v4i *>(sA + (size_t)((r * KS + sft) * KT + kt) * 1024 + lane * 16);
+                const unsigned char *bp = sX + ((size_t)rbase * G::RW + G::X0 - G::P + 16 * strip + col + sft) * G::PXB + 16 * g;
+#pragma unroll
+                for (int yy = 0; yy < 4 + KS - 1; ++yy) {
+                    const v4i bf = *reinterpret_cast<const v4i *>(bp + (size_t)yy * G::RW * G::PXB);
+#pragma unroll
+                    for (int r = 0; r < KS; ++r) {
+                        const int o = yy - r;
+                        if (o >= 0 && o < 4) {
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt) {
+#ifndef CM_SKIP_MFMA
+                                acc[o][kt] = mfma16(af[r][kt], bf, acc[o][kt]);
+#else
+                                acc[o][kt] += af[r][kt] ^ bf;
+#endif
+                            }
+                        }
+                    }
+                }
             }
         }
         // ---- epilogue ------------------------------------------------------------------------------------
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            const int gy = y0 + 2 * wv + (pt >> 1), gx = x0 + 16 * (pt & 1) + col;
+            const int gy = y0 + rbase + pt, gx = x0 + 16 * strip + col;
             if (gy >= H || gx >= W) continue;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
@@ -175,10 +267,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
                 }
                 if (ch0 + 4 <= a.cout) {
                     amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#ifndef CM_SKIP_STORE
                     if (a.u) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) a.u[((size_t)(ch0 + i) * H + gy) * W + gx] = v[i];
                     }
+#endif
                     if (a.q) {
                         unsigned pk = 0;
 #pragma unroll
@@ -201,15 +295,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
     }
 }
 
-template <int KS, int CIN, int KT>
-static hipError_t conv_mfma_launch(const ConvArgs &a0, int ncu, hipStream_t s)
+template <int KS, int CIN, int KT, bool VEC>
+static hipError_t conv_mfma_launch_v(const ConvArgs &a0, int ncu, hipStream_t s)
 {
     ConvArgs a = a0;
     a.tiles_x = (a.W + cm::TW - 1) / cm::TW;
     a.ntiles = a.tiles_x * ((a.H + cm::TH - 1) / cm::TH);
-    const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;
-    hipLaunchKernelGGL((k_conv_mfma<KS, CIN, KT>), dim3(grid), dim3(256), 0, s, a);
+    // persistent grid: as many workgroups as the device keeps resident (registers and LDS of this instantiation)
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma<KS, CIN, KT, VEC>, 256, 0) != hipSuccess || n < 1) n = 2;
+        per_cu = n;
+    }
+    const int grid = a.ntiles < per_cu * ncu ? a.ntiles : per_cu * ncu;
+    hipLaunchKernelGGL((k_conv_mfma<KS, CIN, KT, VEC>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+template <int KS, int CIN, int KT>
+static hipError_t conv_mfma_launch(const ConvArgs &a, int ncu, hipStream_t s)
+{
+    return conv_mfma_launch_v<KS, CIN, KT, false>(a, ncu, s);
 }
 
 bool conv_mfma_supported(int cin, int cout, int ks)

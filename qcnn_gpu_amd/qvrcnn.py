@@ -78,6 +78,11 @@ class qvrcnn:
         capi.check(self._lib.qcnn_forward(self._h))
         return 0
 
+    def forward_layered(self) -> int:
+        """The dynamic pass with every float32 u materialised (tap mode)."""
+        capi.check(self._lib.qcnn_forward_layered(self._h))
+        return 0
+
     def dynamic_state(self) -> "capi.DynamicState":
         st = capi.DynamicState()
         capi.check(self._lib.qcnn_dynamic_state(self._h, C.byref(st)))

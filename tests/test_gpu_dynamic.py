@@ -19,27 +19,43 @@ U_TAPS = [capi.TAP_U_C1, capi.TAP_U_C2_1, capi.TAP_U_C2_2, capi.TAP_U_C3_1, capi
 
 
 def _check_forward(net, mb, y, taps=True):
+    """qcnn_forward (no float images, convolutions run twice) and, with taps, qcnn_forward_layered (every u
+    materialised) against the oracle."""
     rec_o, t = c_oracle.forward_dynamic(mb, y, True)
     net.load_data(y)
     net.forward()
     net.synchronize()
+    _check_state(net, t)
+    for tp, key in ((capi.TAP_V_C1, "v1"), (capi.TAP_CONC1, "conc1"), (capi.TAP_CONC2, "conc2"), (capi.TAP_V_C4, "v4")):
+        bad = np.argwhere(net.tap(tp) != t[key])
+        assert bad.size == 0, f"{key} differs at {bad[:5].tolist()} ({len(bad)} bytes)"
+    assert np.array_equal(net.tap(capi.TAP_U_C4).view(np.uint32), t["u"][5].view(np.uint32))
+    rec = net.download()
+    bad = np.argwhere(rec != rec_o)
+    assert bad.size == 0, f"x_rec differs at {bad[:5].tolist()} ({len(bad)} pixels)"
+    if not taps:
+        return rec_o, t
+    capi.check(capi.load().qcnn_dev_memset(net.x_rec_ptr, 0, rec.size))
+    net.forward_layered()
+    net.synchronize()
+    _check_state(net, t)
+    assert np.array_equal(net.tap(capi.TAP_X_PPRO), t["x_ppro"])
+    for l, tp in enumerate(U_TAPS):
+        assert np.array_equal(net.tap(tp).view(np.uint32), t["u"][l].view(np.uint32)), f"u[{l}]"
+    assert np.array_equal(net.tap(capi.TAP_V_C1), t["v1"])
+    assert np.array_equal(net.tap(capi.TAP_CONC1), t["conc1"])
+    assert np.array_equal(net.tap(capi.TAP_CONC2), t["conc2"])
+    assert np.array_equal(net.tap(capi.TAP_V_C4), t["v4"])
+    assert np.array_equal(net.download(), rec_o)
+    return rec_o, t
+
+
+def _check_state(net, t):
     st = net.dynamic_state()
     assert list(st.max_u) == t["max_u"].tolist()
     assert list(st.step_y) == t["step_y"].tolist()
     assert list(st.stepw) == t["stepw"].tolist() and list(st.stepy) == t["stepy"].tolist()
     assert np.array_equal(np.array(st.b_adj, np.float32).view(np.uint32), t["b_adj"].view(np.uint32))
-    if taps:
-        assert np.array_equal(net.tap(capi.TAP_X_PPRO), t["x_ppro"])
-        for l, tp in enumerate(U_TAPS):
-            assert np.array_equal(net.tap(tp).view(np.uint32), t["u"][l].view(np.uint32)), f"u[{l}]"
-        assert np.array_equal(net.tap(capi.TAP_V_C1), t["v1"])
-        assert np.array_equal(net.tap(capi.TAP_CONC1), t["conc1"])
-        assert np.array_equal(net.tap(capi.TAP_CONC2), t["conc2"])
-        assert np.array_equal(net.tap(capi.TAP_V_C4), t["v4"])
-    rec = net.download()
-    bad = np.argwhere(rec != rec_o)
-    assert bad.size == 0, f"x_rec differs at {bad[:5].tolist()} ({len(bad)} pixels)"
-    return rec_o, t
 
 
 @pytest.mark.parametrize("qp", [22, 37])

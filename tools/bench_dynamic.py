@@ -31,6 +31,7 @@ y = synth.synth_frames(h, w, qp)[1][0]
 out = {"workload": f"{w}x{h} Y frame, QP{qp}, resident in HBM", "steps": a.steps}
 with qvrcnn(0, 1, 1, h, w) as net:
     for name, load, run in (("dynamic", lambda: net.load_para(synth.synth_dynamic_model(qp).to_bytes()), net.forward),
+                            ("dynamic_layered", lambda: None, net.forward_layered),
                             ("static_layered", lambda: net.load_static_para(synth.synth_model(qp).to_nchw_vect_c_bytes()),
                              net.forward_blu_layered)):
         load()
