@@ -134,6 +134,28 @@ typedef struct {
 } qcnn_dynamic_state_t;
 int qcnn_dynamic_state(qcnn_t *e, qcnn_dynamic_state_t *out);
 
+/* ---- float32 configuration ---------------------------------------------------------------- */
+/* The reference's compile-time alternative FLOAT_CONFIG (inference/mat.cuh:42,89-101): activations and
+ * weights float32 NCHW.  Here it is a third model an engine can hold beside the int8 one.
+ * qvrcnn::load_para -> CovLayer::load_para, inference/cnn.cu:114-127: per layer ks*ks*cin*cout float32
+ * weights [K][C][R][S] and outChannel float32 biases (the NCHW_MODEL file of inference/kernel.cu:9;
+ * 218 692 bytes). */
+int qcnn_load_float(qcnn_t *e, const char *path);
+int qcnn_load_float_mem(qcnn_t *e, const void *image, size_t bytes);
+
+/* qvrcnn::forward of that configuration, inference/qvrcnn.cu:244-285: FLOAT_PPRO, six float32 convolutions
+ * on the f32 matrix instructions with bias and ReLU (all layers but C4) in their epilogues, the branch
+ * pairs writing straight into Conc1.conc / Conc2.conc, then applyRes.  Asynchronous on the engine stream.
+ * Float results depend on the summation order, which the reference leaves to cuDNN: parity is by
+ * tolerance (see tests/test_gpu_float.py), not bit-exact. */
+int qcnn_forward_float(qcnn_t *e);
+
+/* Device addresses of CovLayer::w / b / u of layer l in the float configuration (C2_x.u and C3_x.u are
+ * the channel ranges of Conc1.conc / Conc2.conc). */
+void *qcnn_float_w_device_ptr(qcnn_t *e, int layer);
+void *qcnn_float_b_device_ptr(qcnn_t *e, int layer);
+void *qcnn_float_u_device_ptr(qcnn_t *e, int layer);
+
 /* cudaDeviceSynchronize() of inference/kernel.cu:95, restricted to the engine stream. */
 int qcnn_sync(qcnn_t *e);
 
@@ -170,7 +192,13 @@ enum {
     /* after qcnn_forward_blu (fused path): the one intermediate it keeps in HBM, converted
      * back to the reference layout of Conc1.conc */
     QCNN_TAP_FUSED_CONC1 = 11,
-    QCNN_TAP_V_C4 = 12   /* int8  [H][W]                 C4.v after qcnn_forward (adjustOutput)      */
+    QCNN_TAP_V_C4 = 12,  /* int8  [H][W]                 C4.v after qcnn_forward (adjustOutput)      */
+    /* after qcnn_forward_float */
+    QCNN_TAP_F_X_PPRO = 13, /* float [H][W]              I1.x_ppro                        */
+    QCNN_TAP_F_U_C1 = 14,   /* float [64][H][W]          C1.u (after ReLU)                */
+    QCNN_TAP_F_CONC1 = 15,  /* float [48][H][W]          Conc1.conc                       */
+    QCNN_TAP_F_CONC2 = 16,  /* float [48][H][W]          Conc2.conc                       */
+    QCNN_TAP_F_U_C4 = 17    /* float [1][H][W]           C4.u                             */
 };
 int qcnn_tap_bytes(qcnn_t *e, int tap, size_t *bytes);
 int qcnn_tap(qcnn_t *e, int tap, void *host_out, size_t bytes);
@@ -258,6 +286,19 @@ int qcnn_op_adjust_output_static(const void *o, void *o_adj, int mul, int shift,
  * res int8[n]. */
 int qcnn_op_apply_res(const void *x, const void *res, void *rec, size_t n, void *stream);
 
+/* FLOAT_PPRO, inference/cnn.cu:470-484: x_ppro[i] = ((float)x[i] - 128) / 255.  x: uint8[n]; x_ppro: float[n]. */
+int qcnn_op_ppro_float(const void *x, void *x_ppro, size_t n, void *stream);
+
+/* CovLayer::ConvForward of the float configuration, inference/cnn.cu:129-144 (+ CovLayer::activate,
+ * inference/cnn.cu:161-166, when relu != 0): u = conv(x, w) + b.  x: float NCHW [cin][H][W];
+ * w: float [cout][cin][ks][ks]; b: float[cout]; u: float NCHW [cout][H][W].  ks in {1,3,5}, cin in
+ * {1 (ks 5 only), 48, 64}, cout <= 64. */
+int qcnn_op_conv_float(const void *x, const void *w, const void *b, void *u, int height, int width, int cin, int cout,
+                       int ks, int relu, void *stream);
+
+/* applyRes_GPU, float arm, inference/cnn.cu:487-502: rec = clamp((short)(x + res*255 + 0.5), 0, 255). */
+int qcnn_op_apply_res_float(const void *x, const void *res, void *rec, size_t n, void *stream);
+
 /* The step selection of ConcatLayer::concat, inference/cnn.cu:295-309 (host only): one step per branch
  * from its own maximum (1 if the maximum fits in 127), then the finer branch coarsened so that
  * step_w * step_y of both branches agree. */
@@ -280,6 +321,11 @@ long qcnn_hwcn2nchw_vect_c(const int8_t *hwcn, int h, int w, int c, int n, int8_
 /* model_qfp_HWCN2NCHW_VECT_C, inference/qvrcnn.cu:558-585, file to file.  `qp` is substituted
  * into both printf-style patterns as the reference does. */
 int qcnn_model_qfp_hwcn2nchw_vect_c(const char *filein, const char *fileout, int qp);
+
+/* HWCN2NCHW_CPU, inference/mat.cu:160-176 (float weights): out[n][c][h][w] = in[h][w][c][n]. */
+long qcnn_hwcn2nchw(const float *hwcn, int h, int w, int c, int n, float *out);
+/* model_HWCN2NCHW, inference/qvrcnn.cu:464-491 (float configuration), file to file. */
+int qcnn_model_hwcn2nchw(const char *filein, const char *fileout, int qp);
 
 #ifdef __cplusplus
 }

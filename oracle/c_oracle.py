@@ -28,7 +28,7 @@ class _DynTaps(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("qcnn_oracle.c", "qcnn_oracle_dyn.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("qcnn_oracle.c", "qcnn_oracle_dyn.c", "qcnn_oracle_float.c")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libqcnn_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB
@@ -94,6 +94,19 @@ def lib():
         L.orc_forward_dynamic.restype = i
         L.orc_forward_dynamic.argtypes = [vp, lg, vp, i, i, vp, vp]
         L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orf_model_bytes.restype = lg
+        L.orf_ppro.restype = None
+        L.orf_ppro.argtypes = [vp, vp, lg]
+        L.orf_conv.restype = None
+        L.orf_conv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i]
+        L.orf_apply_res_one.restype = C.c_uint8
+        L.orf_apply_res_one.argtypes = [C.c_uint8, f]
+        L.orf_apply_res.restype = None
+        L.orf_apply_res.argtypes = [vp, vp, vp, lg]
+        L.orf_forward.restype = i
+        L.orf_forward.argtypes = [vp, lg, vp, i, i, vp, vp, vp, vp, vp, vp]
+        L.orf_hwcn2nchw.restype = lg
+        L.orf_hwcn2nchw.argtypes = [vp, i, i, i, i, vp]
         _lib = L
     return _lib
 
@@ -184,4 +197,40 @@ def forward_dynamic(model_bytes: bytes, y: np.ndarray, want_taps: bool = False):
     rc = L.orc_forward_dynamic(_p(mb), mb.size, _p(y), h, w, _p(rec), tp)
     if rc:
         raise ValueError(f"orc_forward_dynamic failed: {rc}")
+    return (rec, taps) if want_taps else rec
+
+
+# ---- float32 configuration (oracle/qcnn_oracle_float.c) ---------------------------------------------------
+F_KS, F_CIN = (5, 3, 5, 3, 1, 3), (1, 64, 64, 48, 48, 48)
+
+
+def conv_float(x: np.ndarray, w: np.ndarray, b: np.ndarray, relu: bool, acc32: bool = False) -> np.ndarray:
+    """x float32 [cin][H][W], w float32 [cout][cin][ks][ks], b float32 [cout] -> u float32 [cout][H][W]."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    cout, cin, ks, _ = w.shape
+    _, h, wd = x.shape
+    u = np.empty((cout, h, wd), np.float32)
+    lib().orf_conv(_p(x), _p(w), _p(b), _p(u), h, wd, cin, cout, ks, int(relu), int(acc32))
+    return u
+
+
+def forward_float(model_bytes: bytes, y: np.ndarray, want_taps: bool = False):
+    """The float32 configuration's forward: y uint8 [H][W] -> rec uint8 [H][W] (and the float taps)."""
+    L = lib()
+    y = np.ascontiguousarray(y, np.uint8)
+    h, w = y.shape
+    rec = np.empty((h, w), np.uint8)
+    mb = np.frombuffer(model_bytes, np.uint8)
+    taps = None
+    ptrs = [None] * 5
+    if want_taps:
+        taps = {"x_ppro": np.empty((h, w), np.float32), "u1": np.empty((64, h, w), np.float32),
+                "conc1": np.empty((48, h, w), np.float32), "conc2": np.empty((48, h, w), np.float32),
+                "u4": np.empty((h, w), np.float32)}
+        ptrs = [_p(taps[k]) for k in ("x_ppro", "u1", "conc1", "conc2", "u4")]
+    rc = L.orf_forward(_p(mb), mb.size, _p(y), h, w, _p(rec), *ptrs)
+    if rc:
+        raise ValueError(f"orf_forward failed: {rc}")
     return (rec, taps) if want_taps else rec

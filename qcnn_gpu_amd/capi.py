@@ -26,10 +26,15 @@ SYMBOLS = (
     "qcnn_load_para", "qcnn_load_para_mem", "qcnn_forward", "qcnn_forward_layered", "qcnn_dynamic_state", "qcnn_op_activate",
     "qcnn_op_find_max", "qcnn_op_quant_div", "qcnn_op_mul_shift", "qcnn_op_adjust_basic", "qcnn_op_adjust_output",
     "qcnn_op_adjust_output_static", "qcnn_op_apply_res", "qcnn_concat_steps", "qcnn_layer_b_adj_device_ptr",
+    # float32 configuration
+    "qcnn_load_float", "qcnn_load_float_mem", "qcnn_forward_float", "qcnn_float_w_device_ptr", "qcnn_float_b_device_ptr",
+    "qcnn_float_u_device_ptr", "qcnn_op_ppro_float", "qcnn_op_conv_float", "qcnn_op_apply_res_float", "qcnn_hwcn2nchw",
+    "qcnn_model_hwcn2nchw",
 )
 
 TAP_X_PPRO, TAP_U_C1, TAP_U_C2_1, TAP_U_C2_2, TAP_U_C3_1, TAP_U_C3_2, TAP_U_C4 = range(7)
 TAP_V_C1, TAP_CONC1, TAP_CONC2, TAP_X_REC, TAP_FUSED_CONC1, TAP_V_C4 = 7, 8, 9, 10, 11, 12
+TAP_F_X_PPRO, TAP_F_U_C1, TAP_F_CONC1, TAP_F_CONC2, TAP_F_U_C4 = 13, 14, 15, 16, 17
 
 
 class DynamicState(C.Structure):
@@ -126,6 +131,18 @@ def load():
     L.qcnn_layer_b_adj_device_ptr.restype = vp
     L.qcnn_layer_b_adj_device_ptr.argtypes = [vp, i]
     L.qcnn_concat_steps.argtypes = [C.c_float, C.c_float, i, i, C.POINTER(i), C.POINTER(i)]
+    L.qcnn_load_float.argtypes = [vp, C.c_char_p]
+    L.qcnn_load_float_mem.argtypes = [vp, vp, sz]
+    L.qcnn_forward_float.argtypes = [vp]
+    for fn in (L.qcnn_float_w_device_ptr, L.qcnn_float_b_device_ptr, L.qcnn_float_u_device_ptr):
+        fn.restype = vp
+        fn.argtypes = [vp, i]
+    L.qcnn_op_ppro_float.argtypes = [vp, vp, sz, vp]
+    L.qcnn_op_conv_float.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, vp]
+    L.qcnn_op_apply_res_float.argtypes = [vp, vp, vp, sz, vp]
+    L.qcnn_hwcn2nchw.restype = C.c_long
+    L.qcnn_hwcn2nchw.argtypes = [vp, i, i, i, i, vp]
+    L.qcnn_model_hwcn2nchw.argtypes = [C.c_char_p, C.c_char_p, i]
     _lib = L
     return L
 

@@ -76,6 +76,11 @@ struct qcnn_engine {
     bool dyn_loaded = false;
     DynState *dyn = nullptr;  // device
     int8_t *v4 = nullptr;     // C4.v: int8 residual [H][W]
+    // float32 configuration (qcnn_load_float / qcnn_forward_float), allocated on first use
+    bool float_ready = false, float_loaded = false;
+    float *f_xp = nullptr, *f_u1 = nullptr, *f_conc1 = nullptr, *f_conc2 = nullptr, *f_u4 = nullptr;
+    float *f_w[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *f_b[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // model
     bool loaded = false;
     bool exact = false;  // true: float-pipeline kernels; false: integer fast path proved safe
@@ -104,6 +109,69 @@ static int ensure_layered(qcnn_engine *e)
     HIP_TRY(hipMalloc(&e->conc1, 48 * e->HW));
     HIP_TRY(hipMalloc(&e->conc2, 48 * e->HW));
     e->layered_ready = true;
+    return QCNN_OK;
+}
+
+// CovLayer::build in the float configuration (inference/cnn.cu:29-35, 60-63): weights ks*ks*cin*cout floats,
+// u float NCHW; x_ppro one float per sample (inference/cnn.cu:426-430).  The two branch outputs of a
+// layer are allocated as one 48-channel image, which is the concatenation (ConcatLayer::concat,
+// inference/cnn.cu:396-402, is then no copy).
+static inline int fwsize(int l) { return L_KS[l] * L_KS[l] * L_CIN[l] * L_COUT[l]; }
+static size_t float_model_bytes()
+{
+    size_t n = 0;
+    for (int l = 0; l < 6; ++l) n += sizeof(float) * ((size_t)fwsize(l) + L_COUT[l]);
+    return n;
+}
+
+static int ensure_float(qcnn_engine *e)
+{
+    if (e->float_ready) return QCNN_OK;
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(hipMalloc(&e->f_xp, sizeof(float) * e->HW));
+    HIP_TRY(hipMalloc(&e->f_u1, sizeof(float) * 64 * e->HW));
+    HIP_TRY(hipMalloc(&e->f_conc1, sizeof(float) * 48 * e->HW));
+    HIP_TRY(hipMalloc(&e->f_conc2, sizeof(float) * 48 * e->HW));
+    HIP_TRY(hipMalloc(&e->f_u4, sizeof(float) * e->HW));
+    for (int l = 0; l < 6; ++l) {
+        HIP_TRY(hipMalloc(&e->f_w[l], sizeof(float) * fwsize(l)));
+        HIP_TRY(hipMalloc(&e->f_b[l], sizeof(float) * L_COUT[l]));
+    }
+    e->float_ready = true;
+    return QCNN_OK;
+}
+
+// CovLayer::u of layer l in the float configuration
+static float *float_u(qcnn_engine *e, int l)
+{
+    switch (l) {
+    case 0: return e->f_u1;
+    case 1: return e->f_conc1;
+    case 2: return e->f_conc1 + 32 * e->HW;
+    case 3: return e->f_conc2;
+    case 4: return e->f_conc2 + 16 * e->HW;
+    default: return e->f_u4;
+    }
+}
+
+// qvrcnn::load_para -> CovLayer::load_para of the float configuration (inference/cnn.cu:114-127): per layer
+// wSize float32 weights [K][C][R][S], then outChannel float32 biases.
+static int load_float_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
+{
+    if (bytes < float_model_bytes())
+        return fail(QCNN_E_FORMAT, "float model image is %zu bytes, expected %zu", bytes, float_model_bytes());
+    int rc = ensure_float(e);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const uint8_t *p = img;
+    for (int l = 0; l < 6; ++l) {
+        HIP_TRY(hipMemcpy(e->f_w[l], p, sizeof(float) * fwsize(l), hipMemcpyHostToDevice));
+        p += sizeof(float) * fwsize(l);
+        HIP_TRY(hipMemcpy(e->f_b[l], p, sizeof(float) * L_COUT[l], hipMemcpyHostToDevice));
+        p += sizeof(float) * L_COUT[l];
+    }
+    e->float_loaded = true;
     return QCNN_OK;
 }
 
@@ -465,6 +533,15 @@ int qcnn_destroy(qcnn_t *e)
     (void)hipFree(e->v4);
     (void)hipFree(e->conc1);
     (void)hipFree(e->conc2);
+    (void)hipFree(e->f_xp);
+    (void)hipFree(e->f_u1);
+    (void)hipFree(e->f_conc1);
+    (void)hipFree(e->f_conc2);
+    (void)hipFree(e->f_u4);
+    for (int l = 0; l < 6; ++l) {
+        (void)hipFree(e->f_w[l]);
+        (void)hipFree(e->f_b[l]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return QCNN_OK;
@@ -825,6 +902,64 @@ static int forward_dynamic(qcnn_engine *e, bool taps)
 int qcnn_forward(qcnn_t *e) { return forward_dynamic(e, false); }
 int qcnn_forward_layered(qcnn_t *e) { return forward_dynamic(e, true); }
 
+int qcnn_load_float_mem(qcnn_t *e, const void *image, size_t bytes)
+{
+    if (!e || !image) return fail(QCNN_E_ARG, "null argument");
+    return load_float_image(e, static_cast<const uint8_t *>(image), bytes);
+}
+
+int qcnn_load_float(qcnn_t *e, const char *path)
+{
+    if (!e || !path) return fail(QCNN_E_ARG, "null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(QCNN_E_IO, "cannot open model file %s", path);
+    std::vector<uint8_t> buf(float_model_bytes());
+    const size_t got = fread(buf.data(), 1, buf.size(), fp);
+    fclose(fp);
+    if (got != buf.size()) return fail(QCNN_E_FORMAT, "%s: short model file (%zu of %zu bytes)", path, got, buf.size());
+    return load_float_image(e, buf.data(), buf.size());
+}
+
+// qvrcnn::forward of the float configuration, inference/qvrcnn.cu:244-285: ppro, C1 + ReLU, (C2_1 || C2_2) + ReLU,
+// concat, (C3_1 || C3_2) + ReLU, concat, C4, applyRes.  The ReLU runs in each convolution's epilogue and the
+// branches write straight into the concatenated image.
+int qcnn_forward_float(qcnn_t *e)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    if (!e->float_loaded) return fail(QCNN_E_STATE, "forward before the float model is loaded");
+    HIP_TRY(hipSetDevice(e->gpu));
+    hipStream_t s = e->stream;
+    const int H = e->H, W = e->W;
+    const size_t HW = e->HW;
+    const uint8_t *y = e->bound_y ? e->bound_y : e->x;
+    uint8_t *rec = e->bound_rec ? e->bound_rec : e->x_rec;
+    auto conv = [&](const float *in, int l, int relu) {
+        return launch_conv_float(in, e->f_w[l], e->f_b[l], float_u(e, l), H, W, L_CIN[l], L_COUT[l], L_KS[l], relu, s);
+    };
+    HIP_TRY(launch_ppro_float(y, e->f_xp, HW, s));
+    HIP_TRY(conv(e->f_xp, 0, 1));
+    HIP_TRY(conv(e->f_u1, 1, 1));
+    HIP_TRY(conv(e->f_u1, 2, 1));
+    HIP_TRY(conv(e->f_conc1, 3, 1));
+    HIP_TRY(conv(e->f_conc1, 4, 1));
+    HIP_TRY(conv(e->f_conc2, 5, 0));
+    HIP_TRY(launch_apply_res_float(y, e->f_u4, rec, HW, s));
+    return QCNN_OK;
+}
+
+void *qcnn_float_w_device_ptr(qcnn_t *e, int layer)
+{
+    return (e && layer >= 0 && layer < 6 && ensure_float(e) == QCNN_OK) ? e->f_w[layer] : nullptr;
+}
+void *qcnn_float_b_device_ptr(qcnn_t *e, int layer)
+{
+    return (e && layer >= 0 && layer < 6 && ensure_float(e) == QCNN_OK) ? e->f_b[layer] : nullptr;
+}
+void *qcnn_float_u_device_ptr(qcnn_t *e, int layer)
+{
+    return (e && layer >= 0 && layer < 6 && ensure_float(e) == QCNN_OK) ? float_u(e, layer) : nullptr;
+}
+
 int qcnn_dynamic_state(qcnn_t *e, qcnn_dynamic_state_t *out)
 {
     if (!e || !out) return fail(QCNN_E_ARG, "null argument");
@@ -905,6 +1040,11 @@ static int tap_info(qcnn_t *e, int tap, void **dev, size_t *bytes)
     case QCNN_TAP_X_REC: *dev = e->bound_rec ? e->bound_rec : e->x_rec; *bytes = HW; return 0;
     case QCNN_TAP_FUSED_CONC1: *dev = e->conc1_int; *bytes = 48 * HW; return 0;
     case QCNN_TAP_V_C4: *dev = e->v4; *bytes = HW; return 0;
+    case QCNN_TAP_F_X_PPRO: *dev = e->f_xp; *bytes = sizeof(float) * HW; return 0;
+    case QCNN_TAP_F_U_C1: *dev = e->f_u1; *bytes = sizeof(float) * 64 * HW; return 0;
+    case QCNN_TAP_F_CONC1: *dev = e->f_conc1; *bytes = sizeof(float) * 48 * HW; return 0;
+    case QCNN_TAP_F_CONC2: *dev = e->f_conc2; *bytes = sizeof(float) * 48 * HW; return 0;
+    case QCNN_TAP_F_U_C4: *dev = e->f_u4; *bytes = sizeof(float) * HW; return 0;
     default: return fail(QCNN_E_ARG, "unknown tap %d", tap);
     }
 }
@@ -919,7 +1059,10 @@ int qcnn_tap_bytes(qcnn_t *e, int tap, size_t *bytes)
 void *qcnn_tap_device_ptr(qcnn_t *e, int tap)
 {
     if (!e) return nullptr;
-    if (tap != QCNN_TAP_X_REC && tap != QCNN_TAP_FUSED_CONC1 && tap != QCNN_TAP_V_C4 && ensure_layered(e)) return nullptr;
+    if (tap >= QCNN_TAP_F_X_PPRO) {
+        if (ensure_float(e)) return nullptr;
+    } else if (tap != QCNN_TAP_X_REC && tap != QCNN_TAP_FUSED_CONC1 && tap != QCNN_TAP_V_C4 && ensure_layered(e))
+        return nullptr;
     void *dev = nullptr;
     size_t bytes;
     if (tap_info(e, tap, &dev, &bytes)) return nullptr;
@@ -931,7 +1074,7 @@ int qcnn_tap(qcnn_t *e, int tap, void *host_out, size_t bytes)
     if (!e || !host_out) return fail(QCNN_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->gpu));
     if (tap != QCNN_TAP_X_REC && tap != QCNN_TAP_FUSED_CONC1) {
-        int rc = ensure_layered(e);
+        int rc = tap >= QCNN_TAP_F_X_PPRO ? ensure_float(e) : ensure_layered(e);
         if (rc) return rc;
     }
     void *dev = nullptr;
@@ -1133,6 +1276,32 @@ int qcnn_op_apply_res(const void *x, const void *res, void *rec, size_t n, void 
     return QCNN_OK;
 }
 
+int qcnn_op_ppro_float(const void *x, void *x_ppro, size_t n, void *stream)
+{
+    if (!x || !x_ppro) return fail(QCNN_E_ARG, "null pointer");
+    HIP_TRY(launch_ppro_float(x, x_ppro, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_conv_float(const void *x, const void *w, const void *b, void *u, int height, int width, int cin, int cout,
+                       int ks, int relu, void *stream)
+{
+    if (!x || !w || !b || !u) return fail(QCNN_E_ARG, "null pointer");
+    if (height < 1 || width < 1) return fail(QCNN_E_ARG, "bad frame size %dx%d", width, height);
+    if (!conv_float_supported(cin, cout, ks))
+        return fail(QCNN_E_UNSUPPORTED, "float convolution %dx%d, %d -> %d channels is not a layer shape of the network",
+                    ks, ks, cin, cout);
+    HIP_TRY(launch_conv_float(x, w, b, u, height, width, cin, cout, ks, relu, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
+int qcnn_op_apply_res_float(const void *x, const void *res, void *rec, size_t n, void *stream)
+{
+    if (!x || !res || !rec) return fail(QCNN_E_ARG, "null pointer");
+    HIP_TRY(launch_apply_res_float(x, res, rec, n, (hipStream_t)stream));
+    return QCNN_OK;
+}
+
 int qcnn_concat_steps(float max1, float max2, int step_w1, int step_w2, int *stepy1, int *stepy2)
 {
     if (!stepy1 || !stepy2) return fail(QCNN_E_ARG, "null argument");
@@ -1232,6 +1401,47 @@ int qcnn_model_qfp_hwcn2nchw_vect_c(const char *filein, const char *fileout, int
         qcnn_hwcn2nchw_vect_c(win.data(), ks, ks, c, n, wout.data());
         if (fwrite(wout.data(), 1, wout.size(), fo) != wout.size() ||
             fwrite(tail.data(), 4, tail.size(), fo) != tail.size())
+            rc = fail(QCNN_E_IO, "%s: write failed", fn_out);
+    }
+    fclose(fi);
+    fclose(fo);
+    return rc;
+}
+
+long qcnn_hwcn2nchw(const float *hwcn, int h, int w, int c, int n, float *out)
+{
+    if (!hwcn || !out || h < 1 || w < 1 || c < 1 || n < 1) return fail(QCNN_E_ARG, "bad argument");
+    for (int ih = 0; ih < h; ++ih)
+        for (int iw = 0; iw < w; ++iw)
+            for (int ic = 0; ic < c; ++ic)
+                for (int in = 0; in < n; ++in)
+                    out[(((long)in * c + ic) * h + ih) * w + iw] = hwcn[(((long)ih * w + iw) * c + ic) * n + in];
+    return (long)n * c * h * w;
+}
+
+int qcnn_model_hwcn2nchw(const char *filein, const char *fileout, int qp)
+{
+    if (!filein || !fileout) return fail(QCNN_E_ARG, "null argument");
+    char fn_in[512], fn_out[512];
+    snprintf(fn_in, sizeof fn_in, filein, qp);
+    snprintf(fn_out, sizeof fn_out, fileout, qp);
+    FILE *fi = fopen(fn_in, "rb");
+    if (!fi) return fail(QCNN_E_IO, "failed to open file %s", fn_in);
+    FILE *fo = fopen(fn_out, "wb");
+    if (!fo) {
+        fclose(fi);
+        return fail(QCNN_E_IO, "failed to open file %s", fn_out);
+    }
+    int rc = QCNN_OK;
+    for (int l = 0; l < 6 && rc == QCNN_OK; ++l) {
+        const int ks = L_KS[l], c = L_CIN[l], n = L_COUT[l];
+        std::vector<float> win((size_t)fwsize(l)), wout((size_t)fwsize(l)), b(n);
+        if (fread(win.data(), 4, win.size(), fi) != win.size() || fread(b.data(), 4, b.size(), fi) != b.size()) {
+            rc = fail(QCNN_E_FORMAT, "%s: short HWCN model file at layer %d", fn_in, l);
+            break;
+        }
+        qcnn_hwcn2nchw(win.data(), ks, ks, c, n, wout.data());
+        if (fwrite(wout.data(), 4, wout.size(), fo) != wout.size() || fwrite(b.data(), 4, b.size(), fo) != b.size())
             rc = fail(QCNN_E_IO, "%s: write failed", fn_out);
     }
     fclose(fi);

@@ -166,6 +166,13 @@ hipError_t launch_conc_to_ref(const void *conc_internal, void *conc_ref, int H, 
 hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s);
 hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s);
 
+// float32 configuration (kernels_float.hip)
+bool conv_float_supported(int cin, int cout, int ks);
+hipError_t launch_conv_float(const void *x, const void *w, const void *b, void *u, int H, int W, int cin, int cout,
+                             int ks, int relu, hipStream_t s);
+hipError_t launch_ppro_float(const void *x, void *xf, size_t n, hipStream_t s);
+hipError_t launch_apply_res_float(const void *x, const void *res, void *rec, size_t n, hipStream_t s);
+
 Requant make_requant(int blu, int mul, int shift);
 
 }  // namespace qcnn

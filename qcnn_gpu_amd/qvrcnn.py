@@ -32,6 +32,11 @@ _TAP_SHAPES = {
     capi.TAP_X_REC: (np.uint8, lambda h, w: (h, w)),
     capi.TAP_FUSED_CONC1: (np.int8, lambda h, w: (12, h, w, 4)),
     capi.TAP_V_C4: (np.int8, lambda h, w: (h, w)),
+    capi.TAP_F_X_PPRO: (np.float32, lambda h, w: (h, w)),
+    capi.TAP_F_U_C1: (np.float32, lambda h, w: (64, h, w)),
+    capi.TAP_F_CONC1: (np.float32, lambda h, w: (48, h, w)),
+    capi.TAP_F_CONC2: (np.float32, lambda h, w: (48, h, w)),
+    capi.TAP_F_U_C4: (np.float32, lambda h, w: (1, h, w)),
 }
 
 
@@ -87,6 +92,21 @@ class qvrcnn:
         st = capi.DynamicState()
         capi.check(self._lib.qcnn_dynamic_state(self._h, C.byref(st)))
         return st
+
+    def load_float_para(self, filename) -> int:
+        """qvrcnn::load_para of the float32 configuration (inference/cnn.cu:114-127): the NCHW float model."""
+        if isinstance(filename, (bytes, bytearray, memoryview)) and len(filename) > 4096:
+            buf = bytes(filename)
+            capi.check(self._lib.qcnn_load_float_mem(self._h, buf, len(buf)))
+        else:
+            name = filename if isinstance(filename, bytes) else str(filename).encode()
+            capi.check(self._lib.qcnn_load_float(self._h, name))
+        return 0
+
+    def forward_float(self) -> int:
+        """qvrcnn::forward of the float32 configuration (inference/qvrcnn.cu:244-285)."""
+        capi.check(self._lib.qcnn_forward_float(self._h))
+        return 0
 
     # -- additions ---------------------------------------------------------------------------
     def forward_blu_layered(self) -> int:

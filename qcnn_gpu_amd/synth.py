@@ -119,6 +119,20 @@ def synth_dynamic_model(qp: int = 37, step_w=None) -> DynamicModel:
     return DynamicModel([DynamicLayerParams(lp.w, lp.b, int(s)) for lp, s in zip(m.layers, sw)])
 
 
+def synth_float_model(qp: int = 37) -> bytes:
+    """The float32 network that synth_model(qp) quantises, as an NCHW float model image (the file
+    CovLayer::load_para reads in the float configuration, inference/cnn.cu:114-127): per layer float32
+    weights [K][C][R][S] = w_int * stepw and float32 biases b_int * stepw / ratio."""
+    from .quant_tables import QUANT_ROWS
+    m = synth_model(qp)
+    out = bytearray()
+    for lp, row in zip(m.layers, QUANT_ROWS[qp]):
+        stepw, ratio = float(row[0]), float(row[1])
+        out += np.ascontiguousarray((lp.w.astype(np.float64) * stepw).astype("<f4")).tobytes()
+        out += np.ascontiguousarray((lp.b.astype(np.float64) * stepw / ratio).astype("<f4")).tobytes()
+    return bytes(out)
+
+
 def adversarial_model(kind: str) -> StaticModel:
     """Edge-case models.
     'maxmag'   : every weight -128 / +127 so that |acc| crosses 2^24 in C2_2 (float-accumulator path).

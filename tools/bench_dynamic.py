@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the dynamic-quantisation pass (qcnn_forward, qvrcnn::forward of inference/qvrcnn.cu:82-167) and,
-beside it, the layer-by-layer static pass (qcnn_forward_blu_layered) on one resident 1080p Y frame.
+beside it, the layer-by-layer static pass (qcnn_forward_blu_layered) and the float32 configuration
+(qcnn_forward_float, inference/qvrcnn.cu:244-285) on one resident 1080p Y frame.
 Prints one JSON line.  Not the headline benchmark (bench.py is); this path is bound by the float32
 intermediates it has to write for the per-frame maxima: 4 B per output channel and pixel.
 
@@ -33,7 +34,8 @@ with qvrcnn(0, 1, 1, h, w) as net:
     for name, load, run in (("dynamic", lambda: net.load_para(synth.synth_dynamic_model(qp).to_bytes()), net.forward),
                             ("dynamic_layered", lambda: None, net.forward_layered),
                             ("static_layered", lambda: net.load_static_para(synth.synth_model(qp).to_nchw_vect_c_bytes()),
-                             net.forward_blu_layered)):
+                             net.forward_blu_layered),
+                            ("float32", lambda: net.load_float_para(synth.synth_float_model(qp)), net.forward_float)):
         load()
         net.load_data(y)
         for _ in range(a.warmup):
