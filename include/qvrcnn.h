@@ -48,6 +48,10 @@ public:
      * buffers of inference/qvrcnn.cu:168-242 (every u / v / conc is materialised) */
     int forward_blu_layers(void);
     int save_b_adj(const char *filename);                               /* inference/qvrcnn.cu:288-304 */
+    /* The reference's compile-time float32 configuration (FLOAT_CONFIG) as run-time members: load_para of
+     * inference/cnn.cu:114-127 (NCHW float model) and forward of inference/qvrcnn.cu:244-285. */
+    int load_float_para(char *filename);
+    int forward_float(void);
     ~qvrcnn();
 
     int layers;

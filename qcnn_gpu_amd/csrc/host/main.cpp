@@ -51,9 +51,15 @@ static std::vector<int> parse_qps(const char *s)
 // QCNN_DYNAMIC=1 runs the dynamic-quantisation pass instead (the commented-out alternative of the
 // reference's driver, inference/kernel.cu:87,93: load_para + forward); the model file is then the
 // dynamic format (step_w + weights + biases per layer).
+// QCNN_FLOAT=1 runs the float32 configuration (the reference built with FLOAT_CONFIG, inference/kernel.cu:13-14:
+// MODEL_NAME is then the NCHW float model).
 static bool dynamic_mode() { return getenv("QCNN_DYNAMIC") != nullptr; }
-static void load_model(qvrcnn &net, char *model_fn) { dynamic_mode() ? net.load_para(model_fn) : net.load_static_para(model_fn); }
-static void run_frame(qvrcnn &net) { dynamic_mode() ? net.forward() : net.forward_blu(); }
+static bool float_mode() { return getenv("QCNN_FLOAT") != nullptr; }
+static void load_model(qvrcnn &net, char *model_fn)
+{
+    float_mode() ? net.load_float_para(model_fn) : dynamic_mode() ? net.load_para(model_fn) : net.load_static_para(model_fn);
+}
+static void run_frame(qvrcnn &net) { float_mode() ? net.forward_float() : dynamic_mode() ? net.forward() : net.forward_blu(); }
 
 // One worker per GPU: the frame loop of inference/kernel.cu:91-97 over frames g, g+G, g+2G, ...
 static void worker(int gpu, int ngpu, char *model_fn, vrcnn_data *d, int frame, int channel, int height, int width)
@@ -134,7 +140,7 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
 {
     vrcnn_data test_data(frame, height, width);
     long long us;
-    if (getenv("QCNN_PIPELINE") && !dynamic_mode()) {
+    if (getenv("QCNN_PIPELINE") && !dynamic_mode() && !float_mode()) {
         // engines and models are set up before the clock starts (inference/kernel.cu:86-90); the timed
         // region is the pipelined frame loop on every GPU, frames sharded round-robin
         if (ngpu < 1) ngpu = 1;

@@ -102,6 +102,22 @@ int qvrcnn::load_para(char *filename)
     return 0;
 }
 
+int qvrcnn::load_float_para(char *filename)
+{
+    if (qcnn_load_float(engine, filename) != QCNN_OK) {
+        printf("cannot open model file.\n");
+        printf("%s\n", qcnn_last_error());
+        exit(1);
+    }
+    return 0;
+}
+
+int qvrcnn::forward_float(void)
+{
+    check(qcnn_forward_float(engine));
+    return 0;
+}
+
 int qvrcnn::forward(void)
 {
     check(qcnn_forward(engine));

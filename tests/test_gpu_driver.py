@@ -192,3 +192,28 @@ def test_driver_dynamic_mode(tmp_path):
     assert m, r.stdout
     assert m.group(1) == "%.3f" % c_oracle.psnr(anc, ori) and m.group(2) == "%.3f" % c_oracle.psnr(rec_o, ori)
     assert np.array_equal(formats.read_yuv420_luma(str(tmp_path / "recon.yuv"), frames, h, w), rec_o)
+
+
+def test_driver_float_mode(tmp_path):
+    """QCNN_FLOAT=1: the driver as the reference built with FLOAT_CONFIG runs it (inference/kernel.cu:13-14,
+    NCHW float model, load_para + forward of inference/qvrcnn.cu:244-285) over a 2-frame clip.  Tolerance: the
+    reconstructed pixels may differ from the double-accumulating oracle by one grey level on at most 0.1 % of
+    them (float32 summation order), so the printed PSNR may differ in its last decimal by at most 1."""
+    h, w, qp, frames = 64, 96, 27, 2
+    ori, anc = synth.synth_frames(h, w, qp, frames=frames)
+    formats.write_yuv420_luma(str(tmp_path / "seq.yuv"), ori)
+    formats.write_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), anc)
+    fm = synth.synth_float_model(qp)
+    (tmp_path / f"model_{qp}.data").write_bytes(fm)
+    r = _run(tmp_path, h, w, {"QCNN_QPS": str(qp), "QCNN_FRAMES": str(frames), "QCNN_FLOAT": "1",
+                              "QCNN_SAVE_RECON": "recon.yuv"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    rec_o = np.stack([c_oracle.forward_float(fm, a) for a in anc])
+    rec = formats.read_yuv420_luma(str(tmp_path / "recon.yuv"), frames, h, w)
+    d = np.abs(rec.astype(int) - rec_o.astype(int))
+    assert d.max() <= 1 and np.count_nonzero(d) <= max(1, rec.size // 1000)
+    m = re.search(r"\nbefore net:PSNR=([\d.]+)\nafter quantized net:PSNR=([\d.]+)\ntime:(\d+)us\n", r.stdout)
+    assert m, r.stdout
+    assert m.group(1) == "%.3f" % c_oracle.psnr(anc, ori)
+    assert m.group(2) == "%.3f" % c_oracle.psnr(rec, ori)
+    assert abs(float(m.group(2)) - c_oracle.psnr(rec_o, ori)) <= 0.0015
