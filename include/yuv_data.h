@@ -21,6 +21,12 @@ public:
     double psnr_pf(void);                                   /* inference/yuv_data.cpp:98-112 */
     double psnr_frame(const datatype *data, int n);         /* PSNR of frame n of `data` */
     int save_recon_as(char *filename);                      /* inference/yuv_data.cpp:113-128 */
+    /* Chroma extension (the reference skips the chroma bytes, inference/yuv_data.cpp:36-37, and writes zeros
+     * for them, :119-125).  On an object built as (2*frames, height/2, width/2): reads the U and V planes of
+     * every frame of both files as planes 2i and 2i+1; patch_chroma_into() overwrites the zero chroma of a
+     * file written by save_recon_as with this object's recon planes. */
+    int read_chroma(char *orifile, char *inputfile);
+    int patch_chroma_into(char *filename);
     static double psnr_from_sse(unsigned long long sse, long n); /* 10*log10(65025 / (sse/n)), :94-96 */
     ~vrcnn_data(void);
 

@@ -94,8 +94,17 @@ static void worker_clip(int gpu, int ngpu, qvrcnn *net, vrcnn_data *d, int frame
 
 // stdout line, log.txt record and recon_psnr.data double of inference/kernel.cu:105-115
 static void report(vrcnn_data &d, char *input_fn, int frame, int height, int width, long long us,
-                   const std::vector<uint64_t> *sse_before = nullptr, const std::vector<uint64_t> *sse_after = nullptr)
+                   const std::vector<uint64_t> *sse_before = nullptr, const std::vector<uint64_t> *sse_after = nullptr,
+                   bool chroma = false)
 {
+    if (chroma) {
+        // chroma extension: stdout only; log.txt and recon_psnr.data keep the reference's luma records
+        if (getenv("QCNN_PSNR_PF")) d.psnr_pf();
+        printf("chroma before net:PSNR=%.3f\nchroma after quantized net:PSNR=%.3f\nchroma time:%lldus\n", d.psnr(d.input),
+               d.psnr(d.recon), us);
+        if (getenv("QCNN_SAVE_RECON")) d.patch_chroma_into(getenv("QCNN_SAVE_RECON"));
+        return;
+    }
     time_t now = time(0);
     double psnr1, psnr2;
     if (sse_before && sse_after) {
@@ -135,12 +144,17 @@ static void report(vrcnn_data &d, char *input_fn, int frame, int height, int wid
     if (getenv("QCNN_SAVE_RECON")) d.save_recon_as(getenv("QCNN_SAVE_RECON"));
 }
 
+// chroma = true: the same loop over the U and V planes (half size, two per frame) of the two files
 static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, int channel, int height, int width,
-                       int ngpu)
+                       int ngpu, bool chroma = false)
 {
     vrcnn_data test_data(frame, height, width);
+    auto read = [&]() {
+        if (chroma) test_data.read_chroma(ori_fn, input_fn);
+        else test_data.read_data(ori_fn, input_fn);
+    };
     long long us;
-    if (getenv("QCNN_PIPELINE") && !dynamic_mode() && !float_mode()) {
+    if (getenv("QCNN_PIPELINE") && !dynamic_mode() && !float_mode() && !chroma) {
         // engines and models are set up before the clock starts (inference/kernel.cu:86-90); the timed
         // region is the pipelined frame loop on every GPU, frames sharded round-robin
         if (ngpu < 1) ngpu = 1;
@@ -174,7 +188,7 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
             cw = width;
         }
         load_model(*cached, model_fn);
-        test_data.read_data(ori_fn, input_fn);
+        read();
         const long fs = (long)channel * height * width;
         const auto t1 = std::chrono::steady_clock::now();
         for (int i = 0; i < frame; i++) {
@@ -187,7 +201,7 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
     } else {
         // whole frames sharded round-robin, one host thread and one engine per GPU, no communication
         // between GPUs; here the clock includes engine set-up and model load on every GPU
-        test_data.read_data(ori_fn, input_fn);
+        read();
         const auto t1 = std::chrono::steady_clock::now();
         std::vector<std::thread> th;
         for (int g = 0; g < ngpu; ++g)
@@ -195,7 +209,7 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
         for (auto &t : th) t.join();
         us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
     }
-    report(test_data, input_fn, frame, height, width, us);
+    report(test_data, input_fn, frame, height, width, us, nullptr, nullptr, chroma);
 }
 
 static int run_all(char *oriname, char *inputname, int height, int width)
@@ -213,6 +227,11 @@ static int run_all(char *oriname, char *inputname, int height, int width)
         snprintf(model_fn, sizeof model_fn, pattern, qp);                 // inference/kernel.cu:125
         testqvrcnn(oriname, input_fn, model_fn, frames > 0 ? frames : 1, CHANNEL, height, width, ngpu);
         check(qcnn_dev_sync());
+        if (getenv("QCNN_CHROMA")) {
+            // chroma extension: the same network over the half-size U and V planes (4:2:0)
+            testqvrcnn(oriname, input_fn, model_fn, 2 * (frames > 0 ? frames : 1), CHANNEL, height / 2, width / 2, ngpu, true);
+            check(qcnn_dev_sync());
+        }
     }
     return 0;
 }

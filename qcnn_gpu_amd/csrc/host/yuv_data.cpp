@@ -56,6 +56,52 @@ int vrcnn_data::read_data(char *orifile, char *inputfile)
     return 0;
 }
 
+int vrcnn_data::read_chroma(char *orifile, char *inputfile)
+{
+    FILE *orifp = fopen(orifile, "rb"), *inputfp;
+    if (!orifp) {
+        printf("%s\n", orifile);
+        printf("open ori file failed\n");
+        exit(1);
+    }
+    inputfp = fopen(inputfile, "rb");
+    if (!inputfp) {
+        printf("%s\n", inputfile);
+        printf("open input file failed\n");
+        fclose(orifp);
+        exit(1);
+    }
+    const long q = (long)h * w;  // one chroma plane; the luma plane of the frame holds 4q bytes
+    for (int i = 0; i < frame / 2; ++i) {
+        fseek(orifp, sizeof(datatype) * 4 * q, SEEK_CUR);
+        fseek(inputfp, sizeof(datatype) * 4 * q, SEEK_CUR);
+        if (fread(ori + 2 * i * q, sizeof(datatype), 2 * q, orifp) != (size_t)(2 * q) ||
+            fread(input + 2 * i * q, sizeof(datatype), 2 * q, inputfp) != (size_t)(2 * q)) {
+            printf("short read at frame %d\n", i);
+            exit(1);
+        }
+    }
+    fclose(orifp);
+    fclose(inputfp);
+    return 0;
+}
+
+int vrcnn_data::patch_chroma_into(char *filename)
+{
+    FILE *fp = fopen(filename, "r+b");
+    if (!fp) {
+        printf("write file failed\n");
+        return 1;
+    }
+    const long q = (long)h * w;
+    for (int i = 0; i < frame / 2; ++i) {
+        fseek(fp, (long)i * 6 * q + 4 * q, SEEK_SET);
+        fwrite(recon + 2 * i * q, sizeof(datatype), 2 * q, fp);
+    }
+    fclose(fp);
+    return 0;
+}
+
 int vrcnn_data::read_frame(char *orifile, char *inputfile, int n)
 {
     FILE *orifp = fopen(orifile, "rb"), *inputfp;

@@ -217,3 +217,37 @@ def test_driver_float_mode(tmp_path):
     assert m.group(1) == "%.3f" % c_oracle.psnr(anc, ori)
     assert m.group(2) == "%.3f" % c_oracle.psnr(rec, ori)
     assert abs(float(m.group(2)) - c_oracle.psnr(rec_o, ori)) <= 0.0015
+
+
+def test_driver_chroma_extension(tmp_path):
+    """QCNN_CHROMA=1: after the luma pass the driver runs the same network over the half-size U and V planes of
+    the 4:2:0 files and patches them into the reconstruction file (the reference skips chroma and writes zeros,
+    inference/yuv_data.cpp:36-37,119-125).  Bit-exact against the oracle run on every plane; the luma records on
+    stdout, in log.txt and recon_psnr.data are unchanged by the extension."""
+    h, w, qp, frames = 48, 64, 37, 2
+    ori, anc = synth.synth_frames(h, w, qp, frames=frames)
+    # chroma planes: synthetic half-size frames with their own seeds (planes 2i = U, 2i+1 = V of frame i)
+    cori, canc = synth.synth_frames(h // 2, w // 2, qp, frames=2 * frames, seed=0xC0FFEE)
+    for name, lum, chr_ in (("seq.yuv", ori, cori), (f"anchor_Q{qp}.yuv", anc, canc)):
+        with open(tmp_path / name, "wb") as f:
+            for i in range(frames):
+                f.write(lum[i].tobytes() + chr_[2 * i].tobytes() + chr_[2 * i + 1].tobytes())
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    (tmp_path / f"model_{qp}.data").write_bytes(mb)
+    r = _run(tmp_path, h, w, {"QCNN_QPS": str(qp), "QCNN_FRAMES": str(frames), "QCNN_CHROMA": "1",
+                              "QCNN_SAVE_RECON": "recon.yuv"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    rec_y = np.stack([c_oracle.forward_blu(mb, a) for a in anc])
+    rec_c = np.stack([c_oracle.forward_blu(mb, a) for a in canc])
+    m = re.search(r"\nbefore net:PSNR=([\d.]+)\nafter quantized net:PSNR=([\d.]+)\ntime:(\d+)us\n", r.stdout)
+    assert m and m.group(1) == "%.3f" % c_oracle.psnr(anc, ori) and m.group(2) == "%.3f" % c_oracle.psnr(rec_y, ori)
+    m = re.search(r"chroma before net:PSNR=([\d.]+)\nchroma after quantized net:PSNR=([\d.]+)\nchroma time:(\d+)us\n", r.stdout)
+    assert m, r.stdout
+    assert m.group(1) == "%.3f" % c_oracle.psnr(canc, cori) and m.group(2) == "%.3f" % c_oracle.psnr(rec_c, cori)
+    raw = np.fromfile(tmp_path / "recon.yuv", np.uint8).reshape(frames, h * w * 3 // 2)
+    q = h * w // 4
+    for i in range(frames):
+        assert np.array_equal(raw[i, :h * w].reshape(h, w), rec_y[i])
+        assert np.array_equal(raw[i, h * w:h * w + q].reshape(h // 2, w // 2), rec_c[2 * i])
+        assert np.array_equal(raw[i, h * w + q:].reshape(h // 2, w // 2), rec_c[2 * i + 1])
+    assert (tmp_path / "recon_psnr.data").read_bytes() == struct.pack("<d", c_oracle.psnr(rec_y, ori))
