@@ -9,8 +9,8 @@
 // matrix instruction v_mfma_f32_16x16x4_f32 (exact float32: every product is rounded once and added to
 // the accumulator in k order, no wider intermediate).  A 256-thread workgroup owns an 8 x 32 output
 // tile and walks the input channels in chunks of 16: the chunk's planes (with halo, zero outside the
-// frame) and the chunk's weights, gathered from the file order w[K][C][R][S] into lane-ordered A
-// fragments, are staged in LDS; a wave owns two tile rows (four 16-pixel strips) and every output
+// frame) and the chunk's weights, read in file order w[K][C][R][S] (contiguous per output channel) and
+// scattered into lane-ordered A fragments, are staged in LDS; a wave owns two tile rows (four 16-pixel strips) and every output
 // channel.  The k index of one instruction is four input channels at one tap, so that a B fragment is
 // one dword per lane read from four planes, 16 consecutive pixels each (the plane stride is padded to
 // 16 mod 32 dwords: 64 distinct banks).  The single-channel first layer packs four taps into one
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_conv_f32(const FConvArgs a)
     using G = FGeom<KS, CIN>;
     constexpr int TH = cf::TH, TW = cf::TW, RH = G::RH, RW = G::RW, PS = G::PS, CC = G::CC, STEPS = G::STEPS;
     __shared__ float sX[CC * PS];
-    __shared__ float sA[STEPS * MT * 64];
+    __shared__ float sA[STEPS * MT * 65];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W;
@@ -70,34 +70,64 @@ __global__ __launch_bounds__(256) void k_conv_f32(const FConvArgs a)
     // strip t of this wave: tile row 2*wave + (t >> 1), columns 16*(t & 1) .. +15
     const int xlane = (2 * wave) * RW + px + (CIN == 1 ? 0 : kq * PS);
 
+    constexpr int FS = 65;  // fragment stride in dwords: consecutive fragments start one bank apart
     for (int chunk = 0; chunk < G::NCHUNK; ++chunk) {
         const int c0 = chunk * CC;
-        if (chunk) __syncthreads();
+        // All global loads of the chunk are issued before the first LDS store, so their latencies overlap.
         // input planes of the chunk with halo; cudnn pads with zeros (inference/cnn.cu:44-49)
-        for (int idx = tid; idx < CC * RH * RW; idx += 256) {
+        constexpr int NX = (CC * RH * RW + 255) / 256;
+        float xv[NX];
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = it * 256 + tid;
             const int c = idx / (RH * RW), rem = idx % (RH * RW);
             const int ry = rem / RW, rx = rem % RW;
             const int gy = ty0 - G::P + ry, gx = tx0 - G::P + rx;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = a.x[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
-            sX[c * PS + ry * RW + rx] = v;
+            xv[it] = 0.f;
+            if (idx < CC * RH * RW && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                xv[it] = a.x[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
         }
-        // A fragments: lane l of fragment (step, m) holds W[channel 16m + (l & 15)][k = l >> 4]
-        for (int idx = tid; idx < STEPS * MT * 64; idx += 256) {
-            const int l = idx & 63, f = idx >> 6;
-            const int m = f % MT, step = f / MT;
-            const int ch = 16 * m + (l & 15), k = l >> 4;
-            float v = 0.f;
-            if (ch < a.cout) {
+        // Weights of the chunk: for every output channel the CC * KS * KS floats w[ch][c0 ..][.][.] are
+        // contiguous in the file order, so consecutive threads read consecutive addresses; each value goes to
+        // lane (ch & 15) + 16 k of A fragment (step, m): lane l holds W[channel 16m + (l & 15)][k = l >> 4].
+        constexpr int PER_CH = CIN == 1 ? KS * KS : CC * KS * KS;
+        constexpr int NW = (16 * MT * PER_CH + 255) / 256;
+        float wv[NW];
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const int idx = it * 256 + tid;
+            const int ch = idx / PER_CH, j = idx % PER_CH;
+            wv[it] = 0.f;
+            if (idx < 16 * MT * PER_CH && ch < a.cout) wv[it] = a.w[((size_t)ch * CIN + c0) * KS * KS + j];
+        }
+        if (chunk) __syncthreads();  // every wave is done with the previous chunk's tiles
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = it * 256 + tid;
+            const int c = idx / (RH * RW), rem = idx % (RH * RW);
+            if (idx < CC * RH * RW) sX[c * PS + rem] = xv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const int idx = it * 256 + tid;
+            const int ch = idx / PER_CH, j = idx % PER_CH;
+            if (idx < 16 * MT * PER_CH) {
+                int step, k;
                 if constexpr (CIN == 1) {
-                    const int tap = 4 * step + k;
-                    if (tap < KS * KS) v = a.w[(size_t)ch * KS * KS + tap];
+                    step = j >> 2, k = j & 3;  // tap j = 4 step + k
                 } else {
-                    const int cg = step % (CC / 4), rs = step / (CC / 4);
-                    v = a.w[((size_t)ch * CIN + c0 + 4 * cg + k) * KS * KS + rs];
+                    const int c = j / (KS * KS), rs = j % (KS * KS);
+                    step = (c >> 2) * (KS * KS) + rs, k = c & 3;
                 }
+                sA[(step * MT + (ch >> 4)) * FS + (ch & 15) + 16 * k] = wv[it];
             }
-            sA[idx] = v;
+        }
+        if constexpr (CIN == 1) {
+            // taps 25 .. 27 of the last step: zero weights
+            if (tid < 16 * MT * (4 * STEPS - KS * KS)) {
+                const int ch = tid / (4 * STEPS - KS * KS), tap = KS * KS + tid % (4 * STEPS - KS * KS);
+                sA[((tap >> 2) * MT + (ch >> 4)) * FS + (ch & 15) + 16 * (tap & 3)] = 0.f;
+            }
         }
         __syncthreads();
 
@@ -109,7 +139,7 @@ __global__ __launch_bounds__(256) void k_conv_f32(const FConvArgs a)
                 const int off = xlane + (tap / KS) * RW + tap % KS;
                 float af[MT], bf[4];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) af[m] = sA[(step * MT + m) * 64 + lane];
+                for (int m = 0; m < MT; ++m) af[m] = sA[(step * MT + m) * FS + lane];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) bf[t] = sX[off + (t >> 1) * RW + 16 * (t & 1)];
 #pragma unroll
@@ -125,11 +155,11 @@ __global__ __launch_bounds__(256) void k_conv_f32(const FConvArgs a)
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
                     for (int cg = 0; cg < CC / 4; ++cg) {
-                        const int step = (r * KS + s) * (CC / 4) + cg;
+                        const int step = cg * (KS * KS) + r * KS + s;
                         const int off = xlane + 4 * cg * PS + r * RW + s;
                         float af[MT], bf[4];
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) af[m] = sA[(step * MT + m) * 64 + lane];
+                        for (int m = 0; m < MT; ++m) af[m] = sA[(step * MT + m) * FS + lane];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) bf[t] = sX[off + (t >> 1) * RW + 16 * (t & 1)];
 #pragma unroll
@@ -158,6 +188,58 @@ __global__ __launch_bounds__(256) void k_conv_f32(const FConvArgs a)
                 }
             }
         }
+}
+
+// The single-output-channel layer (C4): a matrix instruction would use one of its 16 rows, so this is a
+// plain multiply-add kernel.  One output pixel per thread on the same 8 x 32 tile and 16-channel chunks;
+// the weight addresses are uniform over the wave, so they travel through the scalar unit.
+template <int KS, int CIN>
+__global__ __launch_bounds__(256) void k_conv_f32_one(const FConvArgs a)
+{
+    using G = FGeom<KS, CIN>;
+    constexpr int RH = G::RH, RW = G::RW, PS = G::PS, CC = G::CC;
+    __shared__ float sX[CC * PS];
+    const int tid = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const int ty0 = (blockIdx.x / a.tiles_x) * cf::TH, tx0 = (blockIdx.x % a.tiles_x) * cf::TW;
+    const int py = tid >> 5, px = tid & 31;
+    const float *__restrict__ w = a.w;
+    float acc = 0.f;
+    for (int chunk = 0; chunk < G::NCHUNK; ++chunk) {
+        const int c0 = chunk * CC;
+        constexpr int NX = (CC * RH * RW + 255) / 256;
+        float xv[NX];
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = it * 256 + tid;
+            const int c = idx / (RH * RW), rem = idx % (RH * RW);
+            const int gy = ty0 - G::P + rem / RW, gx = tx0 - G::P + rem % RW;
+            xv[it] = 0.f;
+            if (idx < CC * RH * RW && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                xv[it] = a.x[(size_t)(c0 + c) * HW + (size_t)gy * W + gx];
+        }
+        if (chunk) __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < CC * RH * RW) sX[(idx / (RH * RW)) * PS + idx % (RH * RW)] = xv[it];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+#pragma unroll
+            for (int r = 0; r < KS; ++r)
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    acc = __builtin_fmaf(w[((c0 + c) * KS + r) * KS + s], sX[c * PS + (py + r) * RW + px + s], acc);
+    }
+    const int gy = ty0 + py, gx = tx0 + px;
+    if (gy < H && gx < W) {
+        float val = acc + a.b[0];
+        if (a.relu) val = val > 0.f ? val : (val < 0.f ? 0.f : val);
+        a.u[(size_t)gy * W + gx] = val;
+    }
 }
 
 __global__ void k_ppro_float(const uint8_t *x, float *xf, size_t n)
@@ -213,7 +295,7 @@ constexpr int max_mt()
 {
     using G = FGeom<KS, CIN>;
     int mt = 4;
-    while (mt > 1 && (G::STEPS * mt * 64 + G::CC * G::PS) * 4 > 64 * 1024) --mt;
+    while (mt > 1 && (G::STEPS * mt * 65 + G::CC * G::PS) * 4 > 64 * 1024) --mt;
     return mt;
 }
 
@@ -231,6 +313,12 @@ static hipError_t conv_f32_launch(const FConvArgs &a0, hipStream_t s)
     constexpr int MAXC = 16 * max_mt<KS, CIN>();
     const int tiles = a0.tiles_x * ((a0.H + cf::TH - 1) / cf::TH);
     const size_t HW = (size_t)a0.H * a0.W;
+    if constexpr (CIN != 1) {
+        if (a0.cout == 1) {
+            hipLaunchKernelGGL((k_conv_f32_one<KS, CIN>), dim3(tiles), dim3(256), 0, s, a0);
+            return hipGetLastError();
+        }
+    }
     for (int k0 = 0; k0 < a0.cout; k0 += MAXC) {
         FConvArgs a = a0;
         a.cout = a0.cout - k0 < MAXC ? a0.cout - k0 : MAXC;
