@@ -89,6 +89,12 @@ int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nfra
 int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, int nframes, size_t stride,
                           const uint8_t *host_ori, uint64_t *sse_before, uint64_t *sse_after);
 
+/* Allocates what qcnn_forward_blu_clip needs for a clip of `nframes` frames (copy streams, device rings, the
+ * per-launch scratch; with_sse != 0: the rings of the original too), so that a caller can keep set-up out of
+ * its timed region as inference/kernel.cu:86-90 does (every cudaMalloc of the reference happens in the
+ * constructors, before the timer starts).  Optional: qcnn_forward_blu_clip allocates on demand. */
+int qcnn_clip_reserve(qcnn_t *e, int nframes, int with_sse);
+
 /* Frames that one kernel launch of qcnn_forward_blu_batch covers (the loop of
  * inference/kernel.cu:91-97 has no such knob: it is the price of the intermediate conc1 image,
  * 48*height*width bytes of device scratch per frame of a launch).  set > 0 changes it, current

@@ -687,6 +687,15 @@ static int ensure_clip(qcnn_engine *e, int frames, bool with_ori)
     return QCNN_OK;
 }
 
+int qcnn_clip_reserve(qcnn_t *e, int nframes, int with_sse)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    if (nframes < 1) return QCNN_OK;
+    const int chunk = nframes < e->group ? nframes : e->group;
+    int rc = ensure_clip(e, chunk, with_sse != 0);
+    return rc ? rc : ensure_conc(e, chunk);
+}
+
 int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, int nframes, size_t stride,
                           const uint8_t *host_ori, uint64_t *sse_before, uint64_t *sse_after)
 {
@@ -762,6 +771,7 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
         HIP_TRY_C(hipEventRecord(e->ev_comp[b], e->stream));
         // copy-out stream
         HIP_TRY_C(hipStreamWaitEvent(e->s_out, e->ev_comp[b], 0));
+        // (one linear copy for densely packed frames was measured: no faster on 256 frames, slower on 500)
         HIP_TRY_C(hipMemcpy2DAsync(host_rec + (size_t)i0 * stride, stride, e->ring_out[b], HW, HW, nf, hipMemcpyDeviceToHost,
                                    e->s_out));
         HIP_TRY_C(hipEventRecord(e->ev_out[b], e->s_out));

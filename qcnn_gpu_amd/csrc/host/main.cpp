@@ -162,6 +162,7 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
         for (int g = 0; g < ngpu; ++g) {
             nets.push_back(new qvrcnn(g, 1, channel, height, width));
             nets.back()->load_static_para(model_fn);
+            check(qcnn_clip_reserve(nets.back()->engine, frame > g ? (frame - g + ngpu - 1) / ngpu : 0, 1));
         }
         test_data.read_data(ori_fn, input_fn);
         std::vector<uint64_t> sse_before(frame), sse_after(frame);
