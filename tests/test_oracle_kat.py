@@ -1,6 +1,7 @@
 """Known answers for the oracle, derived by hand from the reference's formulas, plus agreement of
 the two independent restatements (C and numpy).  The reference holds no golden vectors for this
 path ("parity unpinned"): these are what pins the oracle."""
+import os
 import zlib
 
 import numpy as np
@@ -154,3 +155,23 @@ def test_oracles_reproduce_committed_golden(qp, golden_dir):
     assert c_oracle.psnr(rec, case["ori"]) == float(case["psnr_after"])
     m = formats.StaticModel.from_nchw_vect_c_bytes(mb)
     assert np.array_equal(np_oracle.forward_blu(m, case["anchor"]), case["rec"])
+
+
+def test_psnr_against_reference_vectors():
+    """vrcnn_data::psnr (inference/yuv_data.cpp:87-97: 10*log10(65025/mse)) as restated by the C oracle, by
+    the package's host twin and from the device-side integer SSE, against values produced by the reference's
+    own training/PSNR.py (20*log10(255/rmse); tools/make_psnr_golden.py).  The two formulas are the same
+    number up to the last bits of a double: tolerance 1e-12 relative."""
+    import json
+    from qcnn_gpu_amd import formats
+    path = os.path.join(os.path.dirname(__file__), "golden", "psnr_vectors.json")
+    for c in json.load(open(path))["cases"]:
+        rng = np.random.default_rng(c["seed"])
+        h, w = c["shape"]
+        a = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        b = np.clip(a.astype(np.int64) + rng.integers(-c["noise"], c["noise"] + 1, (h, w)), 0, 255).astype(np.uint8)
+        if np.array_equal(a, b):
+            b[0, 0] ^= 1
+        want = c["psnr"]
+        assert abs(c_oracle.psnr(b, a) - want) <= 1e-12 * abs(want)
+        assert abs(formats.psnr_from_sse(c_oracle.sse(b, a), a.size) - want) <= 1e-12 * abs(want)
