@@ -2,6 +2,7 @@
 """Runs the clip-sized benchmark configurations through the QCNN_GPU driver on one GPU and checks a sample
 of the per-frame PSNR lines against the CPU oracle:
 
+  config 3: the four QP models back to back in one process on 1080p, model-switch cost reported
   config 5: 1920x1080 x 500 frames, QP27, per-frame PSNR logged ("PSNR of Frame %d:%f")
   config 4: 3840x2160 x 64 frames, QP32
 
@@ -79,6 +80,34 @@ def run_case(tmp, name, h, w, qp, distinct, repeat, check):
     return out
 
 
+def run_config3(h=1080, w=1920):
+    """config 3: the four QP models loaded back to back into one engine (the reference needs a rebuild per QP,
+    inference/kernel.cu:122), one 1080p frame each, a 96-row band checked against the oracle; reports what a
+    model switch costs (parse + integer-path proof + fragment packing + upload)."""
+    from oracle import c_oracle
+    from qcnn_gpu_amd.qvrcnn import qvrcnn
+    out = {"height": h, "width": w, "qps": {}}
+    with qvrcnn(0, 1, 1, h, w) as net:
+        for rep in range(2):  # second round: every model has been loaded once, nothing is first-use any more
+            for qp in (22, 27, 32, 37):
+                mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+                y = synth.synth_frames(h, w, qp)[1][0]
+                net.synchronize()
+                t0 = time.perf_counter()
+                net.load_static_para(mb)
+                t_load = time.perf_counter() - t0
+                net.load_data(y)
+                t0 = time.perf_counter()
+                net.forward_blu()
+                net.synchronize()
+                t_fwd = time.perf_counter() - t0
+                rec = net.download()
+                rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(y[:96]))
+                out["qps"][str(qp)] = {"model_switch_us": round(t_load * 1e6, 1), "forward_us": round(t_fwd * 1e6, 1),
+                                       "bit_exact_band": bool(np.array_equal(rec[:90], rec_o[:90]))}
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default=None)
@@ -86,7 +115,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(dir=a.scratch)
     try:
-        res = {"config5_1080p_500f_qp27": run_case(tmp, "c5", 1080, 1920, 27, 50, 10, a.check),
+        res = {"config3_four_qps_1080p": run_config3(),
+               "config5_1080p_500f_qp27": run_case(tmp, "c5", 1080, 1920, 27, 50, 10, a.check),
                "config4_4k_64f_qp32": run_case(tmp, "c4", 2160, 3840, 32, 8, 8, a.check)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
