@@ -163,9 +163,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
             }
         }
     };
-    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+    // Workgroup -> tile map.  Workgroups are dealt to the 8 XCDs round robin (blockIdx.x & 7), each XCD with an
+    // L2 of its own: XCD x walks the x-th eighth of the tiles (row-major), so that the halo rows and columns
+    // neighbouring tiles share are fetched from HBM once per XCD band instead of once per tile.
+#ifdef CM_NO_XCD_MAP
+    const bool xcd_map = false;
+#else
+    const bool xcd_map = (gridDim.x & 7) == 0;
+#endif
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    auto tile_at = [&](int it) -> int {  // the it-th tile of this workgroup, -1 when it has none left
+        if (!xcd_map) {
+            const int t = (int)blockIdx.x + it * (int)gridDim.x;
+            return t < a.ntiles ? t : -1;
+        }
+        const int loc = (int)(blockIdx.x >> 3) + it * (int)(gridDim.x >> 3);
+        const int t = (int)(blockIdx.x & 7) * per_xcd + loc;
+        return (loc < per_xcd && t < a.ntiles) ? t : -1;
+    };
+    int tile = tile_at(0);
+    if (tile >= 0) fetch(tile);
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int it = 0; tile >= 0; ++it) {
+        const int next_tile = tile_at(it + 1);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
         lds_barrier();  // the previous tile's readers are done (and the A fragments are complete)
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
             }
         }
         lds_barrier();
-        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+        if (next_tile >= 0) fetch(next_tile);
         // ---- MFMA ----------------------------------------------------------------------------------------
         // A wave owns one 16-pixel strip and four rows of the tile.  For one kernel column s it keeps the A
         // fragments of all kernel rows in registers and walks the 4 + KS - 1 input rows once: the B fragment
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
                 }
             }
         }
+        tile = next_tile;
     }
     if (a.maxbits) {
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_down(amax, off, 64));

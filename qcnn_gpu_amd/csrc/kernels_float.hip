@@ -28,7 +28,7 @@ struct FConvArgs {
     float *u;        // float NCHW [cout][H][W]
     int relu;
     int H, W, cout;
-    int tiles_x;
+    int tiles_x, ntiles;
 };
 
 namespace cf {
@@ -47,6 +47,17 @@ struct FGeom {
     static_assert(PS >= RH * RW && PS % 32 == 16, "plane stride");
 };
 
+// Workgroup -> tile map.  Workgroups are dealt to the 8 XCDs round robin (blockIdx.x & 7) and each XCD has an
+// L2 of its own: XCD x takes the x-th eighth of the tiles (row-major), so the halo that neighbouring tiles
+// share is fetched from HBM once per XCD band, not once per tile.  The grid is 8 * ceil(ntiles / 8)
+// workgroups; returns -1 for the few without a tile.
+__device__ __forceinline__ int xcd_tile(int ntiles)
+{
+    const int per = (ntiles + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    return ((int)(blockIdx.x >> 3) < per && t < ntiles) ? t : -1;
+}
+
 template <int KS, int CIN, int MT>
 __global__ __launch_bounds__(256) void k_conv_f32(const FConvArgs a)
 {
@@ -58,7 +69,9 @@ __global__ __launch_bounds__(256) void k_conv_f32(const FConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
-    const int ty0 = (blockIdx.x / a.tiles_x) * TH, tx0 = (blockIdx.x % a.tiles_x) * TW;
+    const int tile = xcd_tile(a.ntiles);
+    if (tile < 0) return;
+    const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
     const int kq = lane >> 4, px = lane & 15;
 
     f32x4 acc[MT][4];
@@ -202,7 +215,9 @@ __global__ __launch_bounds__(256) void k_conv_f32_one(const FConvArgs a)
     const int tid = threadIdx.x;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
-    const int ty0 = (blockIdx.x / a.tiles_x) * cf::TH, tx0 = (blockIdx.x % a.tiles_x) * cf::TW;
+    const int tile = xcd_tile(a.ntiles);
+    if (tile < 0) return;
+    const int ty0 = (tile / a.tiles_x) * cf::TH, tx0 = (tile % a.tiles_x) * cf::TW;
     const int py = tid >> 5, px = tid & 31;
     const float *__restrict__ w = a.w;
     float acc = 0.f;
@@ -311,7 +326,7 @@ template <int KS, int CIN>
 static hipError_t conv_f32_launch(const FConvArgs &a0, hipStream_t s)
 {
     constexpr int MAXC = 16 * max_mt<KS, CIN>();
-    const int tiles = a0.tiles_x * ((a0.H + cf::TH - 1) / cf::TH);
+    const int tiles = 8 * ((a0.ntiles + 7) / 8);  // grid: see xcd_tile()
     const size_t HW = (size_t)a0.H * a0.W;
     if constexpr (CIN != 1) {
         if (a0.cout == 1) {
@@ -352,6 +367,7 @@ hipError_t launch_conv_float(const void *x, const void *w, const void *b, void *
     a.W = W;
     a.cout = cout;
     a.tiles_x = (W + cf::TW - 1) / cf::TW;
+    a.ntiles = a.tiles_x * ((H + cf::TH - 1) / cf::TH);
     if (cin == 1) return conv_f32_launch<5, 1>(a, s);
     if (cin == 48) return ks == 1 ? conv_f32_launch<1, 48>(a, s) : ks == 3 ? conv_f32_launch<3, 48>(a, s) : conv_f32_launch<5, 48>(a, s);
     return ks == 1 ? conv_f32_launch<1, 64>(a, s) : ks == 3 ? conv_f32_launch<3, 64>(a, s) : conv_f32_launch<5, 64>(a, s);
