@@ -879,14 +879,40 @@ static int forward_dynamic(qcnn_engine *e, bool taps)
         return he;
     };
     // one layer of the trunk: branches a (and c, or -1) read `in`, their quantised outputs are concatenated in `out`
+    // both branches of a layer in one launch (the input tile is staged once); q_a / q_c as in conv()
+    auto conv_pair = [&](const void *x, int la, int lc, int relu, bool want_u, void *q_a, void *q_c) -> hipError_t {
+        auto branch = [&](int l, void *q) {
+            ConvPairBranch b;
+            b.w = e->w_file[l];
+            b.b = badj + BIAS_OFF[l];
+            b.u = want_u ? e->u[l] : nullptr;
+            b.q = q;
+            b.maxbits = q ? nullptr : &st->maxbits[l];
+            b.divisor_dev = q ? &st->step_y[l] : nullptr;
+            b.divisor = 1;
+            b.cout = L_COUT[l];
+            b.ks = L_KS[l];
+            return b;
+        };
+        return launch_conv_mfma_pair(x, L_CIN[la], H, W, relu, branch(la, q_a), branch(lc, q_c), s);
+    };
+    const bool pairs = mfma && getenv("QCNN_NO_PAIR") == nullptr;
     auto layer = [&](const void *in, int a, int c, int relu, int stage, int8_t *out) -> int {
-        HIP_TRY(conv(in, a, relu, taps, nullptr));
-        if (c >= 0) HIP_TRY(conv(in, c, relu, taps, nullptr));
+        const bool pair = pairs && c >= 0 && L_CIN[a] == L_CIN[c] &&
+                          conv_pair_supported(L_CIN[a], L_COUT[a], L_KS[a], L_COUT[c], L_KS[c]);
+        if (pair) {
+            HIP_TRY(conv_pair(in, a, c, relu, taps, nullptr, nullptr));
+        } else {
+            HIP_TRY(conv(in, a, relu, taps, nullptr));
+            if (c >= 0) HIP_TRY(conv(in, c, relu, taps, nullptr));
+        }
         HIP_TRY(launch_dyn_book(st, stage, s));
         int8_t *out_c = out + (size_t)L_COUT[a] * HW;  // legal because outChannel of branch a is a multiple of 4
         if (taps) {
             HIP_TRY(launch_quant_div(e->u[a], out, HW, L_COUT[a], 0, &st->step_y[a], s));
             if (c >= 0) HIP_TRY(launch_quant_div(e->u[c], out_c, HW, L_COUT[c], 0, &st->step_y[c], s));
+        } else if (pair) {
+            HIP_TRY(conv_pair(in, a, c, relu, false, out, out_c));
         } else {
             HIP_TRY(conv(in, a, relu, false, out));
             if (c >= 0) HIP_TRY(conv(in, c, relu, false, out_c));

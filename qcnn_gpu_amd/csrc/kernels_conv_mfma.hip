@@ -51,13 +51,34 @@ struct ConvGeom {
     static_assert(CIN != 1 || KS == 5, "the packed first layer is 5x5");
 };
 
-__device__ __forceinline__ int quant_div_val(float t, float half, float d)
+// Correctly rounded float32 division by a divisor that is uniform over the kernel.  The compiler's expansion
+// of an IEEE division is: scale, reciprocal, two refinement steps of the reciprocal, quotient, and two
+// residual corrections, the last one fused with the unscaling.  The refined reciprocal depends on the
+// divisor only and is computed once (div_recip); with operands that need no scaling (divisors are integers
+// >= 1, dividends below 2^32 in magnitude) the remaining five instructions give the same quotient.
+__device__ __forceinline__ float div_recip(float d)
+{
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y0, 1.f);
+    return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_rn_by(float x, float d, float y)
+{
+    const float q0 = x * y;
+    const float r0 = __builtin_fmaf(-d, q0, x);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-d, q1, x);
+    return __builtin_fmaf(r1, y, q1);
+}
+
+// CHW2CHW_VECT_C of one value (inference/mat.cu:211-226): (t -+ divisor/2) / divisor in float32, clipped, truncated
+__device__ __forceinline__ int quant_div_val(float t, float half, float d, float y)
 {
     if (t < 0.f) {
-        t = __fdiv_rn(t - half, d);
+        t = div_rn_by(t - half, d, y);
         return t < -128.f ? -128 : (int)t;
     }
-    t = __fdiv_rn(t + half, d);
+    t = div_rn_by(t + half, d, y);
     return t > 127.f ? 127 : (int)t;
 }
 
@@ -123,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
         }
     int divisor = a.divisor;
     if (a.q && a.divisor_dev) divisor = *a.divisor_dev;
-    const float dvf = (float)divisor, half = (float)(divisor >> 1);
+    const float dvf = (float)divisor, half = (float)(divisor >> 1), dvy = div_recip(dvf);
     float amax = 0.f;
 
     // The input region of a tile travels global -> registers -> LDS; the loads of the next tile are issued
@@ -296,14 +317,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
                     if (a.q) {
                         unsigned pk = 0;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pk |= (unsigned)(unsigned char)quant_div_val(v[i], half, dvf) << (8 * i);
+                        for (int i = 0; i < 4; ++i) pk |= (unsigned)(unsigned char)quant_div_val(v[i], half, dvf, dvy) << (8 * i);
                         reinterpret_cast<unsigned *>(a.q)[((size_t)(ch0 >> 2) * H + gy) * W + gx] = pk;
                     }
                 } else {
                     for (int i = 0; ch0 + i < a.cout; ++i) {  // ragged last group (C4: one channel)
                         amax = fmaxf(amax, fabsf(v[i]));
                         if (a.u) a.u[((size_t)(ch0 + i) * H + gy) * W + gx] = v[i];
-                        if (a.q) a.q[(((size_t)(ch0 >> 2) * H + gy) * W + gx) * 4 + i] = (int8_t)quant_div_val(v[i], half, dvf);
+                        if (a.q) a.q[(((size_t)(ch0 >> 2) * H + gy) * W + gx) * 4 + i] = (int8_t)quant_div_val(v[i], half, dvf, dvy);
                     }
                 }
             }
@@ -314,6 +335,298 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_down(amax, off, 64));
         if (lane == 0 && amax > 0.f) atomicMax(a.maxbits, __float_as_uint(amax));
     }
+}
+
+// ---- two branches on one input ------------------------------------------------------------------------
+// The layer kernels above are bound by fetching their input tiles, and the two branches of a VRCNN layer
+// (C2_1 || C2_2 on C1.v, C3_1 || C3_2 on Conc1.conc) read the same input: this kernel stages the tile once
+// (with the halo of the larger kernel) and runs both convolutions on it, each with its own weights, bias,
+// outputs, maximum and divisor.  Results are those of two k_conv_mfma launches.
+struct ConvBranch {
+    const int8_t *w;
+    const float *b;
+    float *u;
+    int8_t *q;
+    unsigned *maxbits;
+    const int *divisor_dev;
+    int divisor;
+    int cout;
+};
+struct ConvPairArgs {
+    const int8_t *x;
+    ConvBranch br[2];
+    int relu;
+    int H, W;
+    int tiles_x, ntiles;
+};
+
+// A fragments of one branch, file order -> lane order, into LDS
+template <int KS, int CIN, int KT>
+__device__ __forceinline__ void pair_load_a(unsigned char *sA, const ConvBranch &br, int tid)
+{
+    constexpr int C4 = (CIN + 3) / 4;
+    const int *w32 = reinterpret_cast<const int *>(br.w);
+    for (int item = tid; item < KS * KS * KT * 64; item += 256) {
+        const int ln = item & 63, f = item >> 6;
+        const int kt = f % KT, step = f / KT;
+        const int k = 16 * kt + (ln & 15), gg = ln >> 4;
+        const int r = step / KS, s = step % KS;
+        v4i frag = {0, 0, 0, 0};
+        if (k < br.cout) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = 4 * gg + j;
+                if (c4 < C4) frag[j] = w32[((k * C4 + c4) * KS + r) * KS + s];
+            }
+        }
+        *reinterpret_cast<v4i *>(sA + (size_t)f * 1024 + ln * 16) = frag;
+    }
+}
+
+// One branch on the staged tile: MFMAs of this wave's 4 rows x 16 pixels, then the epilogue.  D = rows /
+// columns by which this branch's window starts inside the region (the region has the larger kernel's halo).
+template <int KS, int KT, int KSM, int CIN>
+__device__ __forceinline__ void pair_branch(const unsigned char *sA, const unsigned char *sX, const ConvBranch &br, int relu,
+                                            int H, int W, int y0, int x0, int lane, int wv, float dvf, float half, float dvy, float &amax)
+{
+    using G = ConvGeom<KSM, CIN>;
+    constexpr int D = (KSM - KS) / 2;
+    const int g = lane >> 4, col = lane & 15;
+    const int strip = wv & 1, rbase = 4 * (wv >> 1);
+    v4i acc[4][KT];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[o][kt] = v4i{0, 0, 0, 0};
+#pragma unroll 1
+    for (int sft = 0; sft < KS; ++sft) {
+        v4i af[KS][KT];
+#pragma unroll
+        for (int r = 0; r < KS; ++r)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                af[r][kt] = *reinterpret_cast<const v4i *>(sA + (size_t)((r * KS + sft) * KT + kt) * 1024 + lane * 16);
+        const unsigned char *bp = sX + ((size_t)(rbase + D) * G::RW + D + 16 * strip + col + sft) * G::PXB + 16 * g;
+#pragma unroll
+        for (int yy = 0; yy < 4 + KS - 1; ++yy) {
+            const v4i bf = *reinterpret_cast<const v4i *>(bp + (size_t)yy * G::RW * G::PXB);
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+                const int o = yy - r;
+                if (o >= 0 && o < 4) {
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[o][kt] = mfma16(af[r][kt], bf, acc[o][kt]);
+                }
+            }
+        }
+    }
+    float bias[KT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = 16 * kt + 4 * g + i;
+            bias[kt][i] = ch < br.cout ? br.b[ch] : 0.f;
+        }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int gy = y0 + rbase + pt, gx = x0 + 16 * strip + col;
+        if (gy >= H || gx >= W) continue;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int ch0 = 16 * kt + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = (float)acc[pt][kt][i] + bias[kt][i];
+                if (relu && t < 0.f) t = 0.f;
+                v[i] = t;
+            }
+            if (ch0 + 4 <= br.cout) {
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                if (br.u) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) br.u[((size_t)(ch0 + i) * H + gy) * W + gx] = v[i];
+                }
+                if (br.q) {
+                    unsigned pk = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pk |= (unsigned)(unsigned char)quant_div_val(v[i], half, dvf, dvy) << (8 * i);
+                    reinterpret_cast<unsigned *>(br.q)[((size_t)(ch0 >> 2) * H + gy) * W + gx] = pk;
+                }
+            } else {
+                for (int i = 0; ch0 + i < br.cout; ++i) {
+                    amax = fmaxf(amax, fabsf(v[i]));
+                    if (br.u) br.u[((size_t)(ch0 + i) * H + gy) * W + gx] = v[i];
+                    if (br.q) br.q[(((size_t)(ch0 >> 2) * H + gy) * W + gx) * 4 + i] = (int8_t)quant_div_val(v[i], half, dvf, dvy);
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int KSA, int KTA, int KSB, int KTB>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma_pair(const ConvPairArgs a)
+{
+    constexpr int KSM = KSA > KSB ? KSA : KSB;
+    using G = ConvGeom<KSM, CIN>;
+    constexpr int TH = cm::TH, TW = cm::TW;
+    static_assert(CIN == 48 || CIN == 64, "the paired layers read 48 or 64 channels");
+    __shared__ __attribute__((aligned(16))) unsigned char sAa[KSA * KSA * KTA * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char sAb[KSB * KSB * KTB * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char sX[G::SX_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = a.H, W = a.W;
+    const int *x32 = reinterpret_cast<const int *>(a.x);
+    pair_load_a<KSA, CIN, KTA>(sAa, a.br[0], tid);
+    pair_load_a<KSB, CIN, KTB>(sAb, a.br[1], tid);
+    if (tid < 16) *reinterpret_cast<int *>(sX + G::RH * G::RW * G::PXB + 4 * tid) = 0;  // the slack stays finite
+
+    float dvf[2], half[2], dvy[2], amax[2] = {0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        int divisor = a.br[b].divisor;
+        if (a.br[b].q && a.br[b].divisor_dev) divisor = *a.br[b].divisor_dev;
+        dvf[b] = (float)divisor, half[b] = (float)(divisor >> 1), dvy[b] = div_recip(dvf[b]);
+    }
+
+    // tile fetch: global -> registers (issued one tile ahead) -> LDS, as in k_conv_mfma
+    constexpr int NCOL = G::RW;
+    constexpr int RPP = (256 / NCOL) < G::RH ? (256 / NCOL) : G::RH;
+    constexpr int NCHUNK = (G::RH + RPP - 1) / RPP;
+    constexpr int NGRP = (256 / (NCOL * RPP)) < G::C4 ? (256 / (NCOL * RPP)) : G::C4;
+    constexpr int NC4 = (G::C4 + NGRP - 1) / NGRP;
+    const int fgrp = tid / (NCOL * RPP), fin = tid % (NCOL * RPP);
+    const int fcx = fin % NCOL, fry = fin / NCOL;
+    const size_t plane = (size_t)H * W;
+    int pre[NC4 * NCHUNK];
+    auto fetch = [&](int tile) {
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int gx = tx * TW + fcx - G::X0;
+        const bool colok = fgrp < NGRP && gx >= 0 && gx < W;
+#pragma unroll
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            const int ry = fry + ch * RPP;
+            const int gy = ty * TH + ry - G::P;
+            const bool rowok = colok && ry < G::RH && gy >= 0 && gy < H;
+            const int *src = x32 + ((size_t)gy * W + gx);
+#pragma unroll
+            for (int j = 0; j < NC4; ++j) {
+                const int c4 = fgrp + j * NGRP;
+                int v = 0;
+                if (rowok && c4 < G::C4) v = src[c4 * plane];
+                pre[ch * NC4 + j] = v;
+            }
+        }
+    };
+    const bool xcd_map = (gridDim.x & 7) == 0;
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    auto tile_at = [&](int it) -> int {
+        if (!xcd_map) {
+            const int t = (int)blockIdx.x + it * (int)gridDim.x;
+            return t < a.ntiles ? t : -1;
+        }
+        const int loc = (int)(blockIdx.x >> 3) + it * (int)(gridDim.x >> 3);
+        const int t = (int)(blockIdx.x & 7) * per_xcd + loc;
+        return (loc < per_xcd && t < a.ntiles) ? t : -1;
+    };
+    int tile = tile_at(0);
+    if (tile >= 0) fetch(tile);
+    for (int it = 0; tile >= 0; ++it) {
+        const int next_tile = tile_at(it + 1);
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int y0 = ty * TH, x0 = tx * TW;
+        lds_barrier();
+#pragma unroll
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            const int ry = fry + ch * RPP;
+            if (fgrp < NGRP && ry < G::RH) {
+                unsigned char *dst = sX + (ry * G::RW + fcx) * G::PXB;
+#pragma unroll
+                for (int j = 0; j < NC4; ++j) {
+                    const int c4 = fgrp + j * NGRP;
+                    if (c4 < G::C4) *reinterpret_cast<int *>(dst + 4 * c4) = pre[ch * NC4 + j];
+                }
+            }
+        }
+        lds_barrier();
+        if (next_tile >= 0) fetch(next_tile);
+        pair_branch<KSA, KTA, KSM, CIN>(sAa, sX, a.br[0], a.relu, H, W, y0, x0, lane, wv, dvf[0], half[0], dvy[0], amax[0]);
+        pair_branch<KSB, KTB, KSM, CIN>(sAb, sX, a.br[1], a.relu, H, W, y0, x0, lane, wv, dvf[1], half[1], dvy[1], amax[1]);
+        tile = next_tile;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+        if (a.br[b].maxbits) {
+            float m = amax[b];
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+            if (lane == 0 && m > 0.f) atomicMax(a.br[b].maxbits, __float_as_uint(m));
+        }
+}
+
+template <int CIN, int KSA, int KTA, int KSB, int KTB>
+static hipError_t conv_pair_launch(ConvPairArgs a, int ncu, hipStream_t s)
+{
+    a.tiles_x = (a.W + cm::TW - 1) / cm::TW;
+    a.ntiles = a.tiles_x * ((a.H + cm::TH - 1) / cm::TH);
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB>, 256, 0) != hipSuccess || n < 1)
+            n = 1;
+        per_cu = n;
+    }
+    const int grid = a.ntiles < per_cu * ncu ? a.ntiles : per_cu * ncu;
+    hipLaunchKernelGGL((k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+static int device_cus()
+{
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            n > 0)
+            ncu = n;
+        else
+            ncu = 256;
+    }
+    return ncu;
+}
+
+// Branch pairs of the network: (3x3 64->32 || 5x5 64->16) and (3x3 48->16 || 1x1 48->32).
+bool conv_pair_supported(int cin, int cout_a, int ks_a, int cout_b, int ks_b)
+{
+    return (cin == 64 && ks_a == 3 && cout_a == 32 && ks_b == 5 && cout_b == 16) ||
+           (cin == 48 && ks_a == 3 && cout_a == 16 && ks_b == 1 && cout_b == 32);
+}
+
+// Both branches of a layer in one launch; per branch: w, b, u / q / maxbits / divisor_dev as in launch_conv_mfma.
+hipError_t launch_conv_mfma_pair(const void *x, int cin, int H, int W, int relu, const ConvPairBranch &ba, const ConvPairBranch &bb,
+                                 hipStream_t s)
+{
+    if (!conv_pair_supported(cin, ba.cout, ba.ks, bb.cout, bb.ks)) return hipErrorInvalidValue;
+    ConvPairArgs a;
+    a.x = (const int8_t *)x;
+    const ConvPairBranch *src[2] = {&ba, &bb};
+    for (int i = 0; i < 2; ++i) {
+        a.br[i].w = (const int8_t *)src[i]->w;
+        a.br[i].b = (const float *)src[i]->b;
+        a.br[i].u = (float *)src[i]->u;
+        a.br[i].q = (int8_t *)src[i]->q;
+        a.br[i].maxbits = src[i]->maxbits;
+        a.br[i].divisor_dev = src[i]->divisor_dev;
+        a.br[i].divisor = src[i]->divisor;
+        a.br[i].cout = src[i]->cout;
+    }
+    a.relu = relu;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = a.ntiles = 0;
+    if (cin == 64) return conv_pair_launch<64, 3, 2, 5, 1>(a, device_cus(), s);
+    return conv_pair_launch<48, 3, 1, 1, 2>(a, device_cus(), s);
 }
 
 template <int KS, int CIN, int KT, bool VEC>

@@ -145,6 +145,17 @@ bool conv_direct_only();  // QCNN_CONV_DIRECT=1: keep the layer-level convolutio
 hipError_t launch_conv_mfma(const void *x, const void *w, const void *b, void *u, void *q, unsigned *maxbits,
                             const int *divisor_dev, int divisor, int relu, int H, int W, int cin, int cout, int ks,
                             hipStream_t s);
+// Both branches of a layer on one staged input tile (kernels_conv_mfma.hip): the results of two launch_conv_mfma calls.
+struct ConvPairBranch {
+    const void *w, *b;
+    void *u, *q;
+    unsigned *maxbits;
+    const int *divisor_dev;
+    int divisor, cout, ks;
+};
+bool conv_pair_supported(int cin, int cout_a, int ks_a, int cout_b, int ks_b);
+hipError_t launch_conv_mfma_pair(const void *x, int cin, int H, int W, int relu, const ConvPairBranch &ba, const ConvPairBranch &bb,
+                                 hipStream_t s);
 hipError_t launch_absmax(const void *u, size_t n, unsigned *maxbits, hipStream_t s);
 hipError_t launch_relu(void *u, size_t n, hipStream_t s);
 hipError_t launch_quant_div(const void *u, void *out, size_t hw, int channels, int divisor, const int *divisor_dev,

@@ -26,6 +26,7 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--qp", type=int, default=37)
+ap.add_argument("--only", default="", help="comma-separated subset of: dynamic,dynamic_layered,static_layered,float32")
 a = ap.parse_args()
 h, w, qp = a.height, a.width, a.qp
 y = synth.synth_frames(h, w, qp)[1][0]
@@ -36,6 +37,10 @@ with qvrcnn(0, 1, 1, h, w) as net:
                             ("static_layered", lambda: net.load_static_para(synth.synth_model(qp).to_nchw_vect_c_bytes()),
                              net.forward_blu_layered),
                             ("float32", lambda: net.load_float_para(synth.synth_float_model(qp)), net.forward_float)):
+        if a.only and name not in a.only.split(","):
+            if name == "dynamic":
+                load()  # the layered variant runs on the model this one loads
+            continue
         load()
         net.load_data(y)
         for _ in range(a.warmup):
