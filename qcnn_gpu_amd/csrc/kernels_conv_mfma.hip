@@ -398,7 +398,7 @@ __device__ __forceinline__ void pair_branch(const unsigned char *sA, const unsig
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc[o][kt] = v4i{0, 0, 0, 0};
-#pragma unroll 1
+#pragma unroll
     for (int sft = 0; sft < KS; ++sft) {
         v4i af[KS][KT];
 #pragma unroll
