@@ -92,8 +92,11 @@ __device__ __forceinline__ void lds_barrier()
 // VEC (four horizontally adjacent pixels of one vec4 group as one 16-byte load, with the region widened to
 // whole groups) measured slower than dword loads -- 133 against 112 us on the 5x5 64->16 layer at 1080p --
 // and is not instantiated.
-template <int KS, int CIN, int KT, bool VEC>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvArgs a)
+// MINB: workgroups per CU the register allocation must leave room for.  These kernels wait on the fetch of
+// their next tile, so a third resident workgroup pays for itself where the float image is not written (the
+// passes of qcnn_forward); with the float stores it costs more in spills than it hides.
+template <int KS, int CIN, int KT, bool VEC, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_conv_mfma(const ConvArgs a)
 {
     using G = ConvGeom<KS, CIN>;
     constexpr int TH = cm::TH, TW = cm::TW;
@@ -465,8 +468,8 @@ __device__ __forceinline__ void pair_branch(const unsigned char *sA, const unsig
     }
 }
 
-template <int CIN, int KSA, int KTA, int KSB, int KTB>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma_pair(const ConvPairArgs a)
+template <int CIN, int KSA, int KTA, int KSB, int KTB, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_conv_mfma_pair(const ConvPairArgs a)
 {
     constexpr int KSM = KSA > KSB ? KSA : KSB;
     using G = ConvGeom<KSM, CIN>;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_pair(const ConvPairArgs a)
         }
 }
 
-template <int CIN, int KSA, int KTA, int KSB, int KTB>
+template <int CIN, int KSA, int KTA, int KSB, int KTB, int MINB>
 static hipError_t conv_pair_launch(ConvPairArgs a, int ncu, hipStream_t s)
 {
     a.tiles_x = (a.W + cm::TW - 1) / cm::TW;
@@ -573,12 +576,12 @@ static hipError_t conv_pair_launch(ConvPairArgs a, int ncu, hipStream_t s)
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB>, 256, 0) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB, MINB>, 256, 0) != hipSuccess || n < 1)
             n = 1;
         per_cu = n;
     }
     const int grid = a.ntiles < per_cu * ncu ? a.ntiles : per_cu * ncu;
-    hipLaunchKernelGGL((k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB, MINB>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -625,11 +628,12 @@ hipError_t launch_conv_mfma_pair(const void *x, int cin, int H, int W, int relu,
     a.H = H;
     a.W = W;
     a.tiles_x = a.ntiles = 0;
-    if (cin == 64) return conv_pair_launch<64, 3, 2, 5, 1>(a, device_cus(), s);
-    return conv_pair_launch<48, 3, 1, 1, 2>(a, device_cus(), s);
+    if (cin == 64) return conv_pair_launch<64, 3, 2, 5, 1, 2>(a, device_cus(), s);
+    if (a.br[0].u || a.br[1].u) return conv_pair_launch<48, 3, 1, 1, 2, 2>(a, device_cus(), s);
+    return conv_pair_launch<48, 3, 1, 1, 2, 3>(a, device_cus(), s);
 }
 
-template <int KS, int CIN, int KT, bool VEC>
+template <int KS, int CIN, int KT, bool VEC, int MINB = 2>
 static hipError_t conv_mfma_launch_v(const ConvArgs &a0, int ncu, hipStream_t s)
 {
     ConvArgs a = a0;
@@ -639,11 +643,11 @@ static hipError_t conv_mfma_launch_v(const ConvArgs &a0, int ncu, hipStream_t s)
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma<KS, CIN, KT, VEC>, 256, 0) != hipSuccess || n < 1) n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma<KS, CIN, KT, VEC, MINB>, 256, 0) != hipSuccess || n < 1) n = 2;
         per_cu = n;
     }
     const int grid = a.ntiles < per_cu * ncu ? a.ntiles : per_cu * ncu;
-    hipLaunchKernelGGL((k_conv_mfma<KS, CIN, KT, VEC>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_conv_mfma<KS, CIN, KT, VEC, MINB>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -689,7 +693,8 @@ hipError_t launch_conv_mfma(const void *x, const void *w, const void *b, void *u
     a.W = W;
     a.cout = cout;
     a.tiles_x = a.ntiles = 0;
-    if (ks == 5 && cin == 1 && cout == 64) return conv_mfma_launch<5, 1, 4>(a, ncu, s);
+    if (ks == 5 && cin == 1 && cout == 64)
+        return a.u ? conv_mfma_launch_v<5, 1, 4, false, 2>(a, ncu, s) : conv_mfma_launch_v<5, 1, 4, false, 3>(a, ncu, s);
     if (ks == 3 && cin == 64 && cout == 32) return conv_mfma_launch<3, 64, 2>(a, ncu, s);
     if (ks == 5 && cin == 64 && cout == 16) return conv_mfma_launch<5, 64, 1>(a, ncu, s);
     if (ks == 3 && cin == 48 && cout == 16) return conv_mfma_launch<3, 48, 1>(a, ncu, s);
