@@ -92,7 +92,7 @@ __device__ __forceinline__ void lds_barrier()
 // VEC (four horizontally adjacent pixels of one vec4 group as one 16-byte load, with the region widened to
 // whole groups) measured slower than dword loads -- 133 against 112 us on the 5x5 64->16 layer at 1080p --
 // and is not instantiated.
-// MINB: workgroups per CU the register allocation must leave room for.  These kernels wait on the fetch of
+// MINB: waves per SIMD (= resident 256-thread workgroups per CU) the register allocation must leave room for.  These kernels wait on the fetch of
 // their next tile, so a third resident workgroup pays for itself where the float image is not written (the
 // passes of qcnn_forward); with the float stores it costs more in spills than it hides.
 template <int KS, int CIN, int KT, bool VEC, int MINB>
