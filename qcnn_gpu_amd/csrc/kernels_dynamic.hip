@@ -142,18 +142,48 @@ hipError_t launch_adjust_basic(const DynSteps &st, const void *b, void *b_adj, i
     return hipGetLastError();
 }
 
+// num / d truncated toward zero, as the reference's long long division does.  The four divisors are uniform
+// over the kernel, so their reciprocals are computed once, in double: below 2^51 the product num * (1/d) is
+// within one of the quotient, and the remainder (exact in 64-bit integers) says in which direction to
+// correct.  Larger dividends take the 64-bit division itself.
+__device__ __forceinline__ long long div_trunc_by(long long num, int d, double inv)
+{
+    const long long mag = num < 0 ? -num : num;
+    if (mag >= (1ll << 51)) return num / d;
+    long long q = (long long)((double)num * inv);
+    long long r = num - q * d;
+    if (r >= d) {
+        q += 1;
+        r -= d;
+    } else if (r <= -(long long)d) {
+        q -= 1;
+        r += d;
+    }
+    if (num >= 0 && r < 0) q -= 1;
+    else if (num < 0 && r > 0) q += 1;
+    return q;
+}
+
 // adjustOutput (inference/qvrcnn.cu:368-385).  The steps come from device memory when st_dev is not null.
 __global__ __launch_bounds__(256) void k_adjust_output(DynSteps st, const DynSteps *st_dev, const float *__restrict__ o,
                                                        int8_t *__restrict__ o_adj, int n, size_t num)
 {
     if (st_dev) st = *st_dev;
+    double inv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) inv[k] = k < n && st.stepw[k] != 0 ? 1.0 / (double)st.stepw[k] : 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < num; i += (size_t)gridDim.x * 256) {
         long long temp = (long long)o[i];
         for (int k = 0; k < n - 1; ++k) temp *= st.stepy[k];
-        if (temp > 0)
-            for (int k = n - 1; k >= 0; --k) temp = (temp + (st.stepw[k] >> 1)) / st.stepw[k];
-        else
-            for (int k = n - 1; k >= 0; --k) temp = (temp - (st.stepw[k] >> 1)) / st.stepw[k];
+        if (temp > 0) {
+#pragma unroll
+            for (int k = 3; k >= 0; --k)
+                if (k < n) temp = div_trunc_by(temp + (st.stepw[k] >> 1), st.stepw[k], inv[k]);
+        } else {
+#pragma unroll
+            for (int k = 3; k >= 0; --k)
+                if (k < n) temp = div_trunc_by(temp - (st.stepw[k] >> 1), st.stepw[k], inv[k]);
+        }
         o_adj[i] = (int8_t)temp;
     }
 }

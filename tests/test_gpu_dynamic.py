@@ -220,6 +220,18 @@ def test_dynamic_layer_ops_on_raw_pointers():
         do = dev(np.zeros_like(ref))
         capi.check(lib.qcnn_op_adjust_output(stepw.ctypes.data, stepy.ctypes.data, dev(o), do, n, o.size, None))
         assert np.array_equal(back(do, ref), ref), f"adjust_output n={n}"
+    # wide dividends: products beyond 2^51 take the 64-bit division, the later stages the reciprocal path; small
+    # divisors and exact multiples sit on the truncation boundaries
+    o_w = np.concatenate([rng.integers(-2 ** 19, 2 ** 19, 20000), np.arange(-3000, 3000), [0, 1, -1]]).astype(np.float32)
+    for sw_, sy_, n in (((7, 3, 2, 1), (20000, 30000, 10000, 0), 4), ((1, 1, 1, 1), (1, 1, 1, 0), 4),
+                        ((1000003, 65537, 4099, 17), (20000, 30000, 10000, 0), 4), ((12, 5, 0, 0), (6, 0, 0, 0), 2),
+                        ((2, 0, 0, 0), (0, 0, 0, 0), 1)):
+        sw_, sy_ = np.array(sw_, np.int32), np.array(sy_, np.int32)
+        ref = np.empty(o_w.size, np.int8)
+        L.orc_adjust_output(sw_.ctypes.data, sy_.ctypes.data, o_w.ctypes.data, ref.ctypes.data, n, o_w.size)
+        do = dev(np.zeros_like(ref))
+        capi.check(lib.qcnn_op_adjust_output(sw_.ctypes.data, sy_.ctypes.data, dev(o_w), do, n, o_w.size, None))
+        assert np.array_equal(back(do, ref), ref), f"adjust_output wide {sw_.tolist()}"
     ref = np.empty(o.size, np.int8)
     L.orc_adjust_output_static(o.ctypes.data, ref.ctypes.data, 141, 16, o.size)
     do = dev(np.zeros_like(ref))
