@@ -87,7 +87,8 @@ struct qcnn_engine {
     int force_exact = 0;
     Requant rq[6];
     // clip pipeline (qcnn_forward_blu_clip): copy streams, two-deep device rings, hand-off events
-    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr, s_ori = nullptr;
+    hipEvent_t ev_ori[2] = {nullptr, nullptr};
     uint8_t *ring_in[2] = {nullptr, nullptr}, *ring_out[2] = {nullptr, nullptr}, *ring_ori[2] = {nullptr, nullptr};
     int ring_frames = 0;  // capacity of each ring slot, in frames
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
@@ -521,6 +522,9 @@ int qcnn_destroy(qcnn_t *e)
         if (e->ev_out[b]) (void)hipEventDestroy(e->ev_out[b]);
     }
     if (e->s_in) (void)hipStreamDestroy(e->s_in);
+    if (e->s_ori) (void)hipStreamDestroy(e->s_ori);
+    for (int b = 0; b < 2; ++b)
+        if (e->ev_ori[b]) (void)hipEventDestroy(e->ev_ori[b]);
     if (e->s_out) (void)hipStreamDestroy(e->s_out);
     (void)hipFree(e->dbg);
     (void)hipFree(e->x_ppro);
@@ -660,11 +664,13 @@ static int ensure_clip(qcnn_engine *e, int frames, bool with_ori)
 {
     HIP_TRY(hipSetDevice(e->gpu));
     if (!e->s_in) HIP_TRY(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+    if (!e->s_ori) HIP_TRY(hipStreamCreateWithFlags(&e->s_ori, hipStreamNonBlocking));
     if (!e->s_out) HIP_TRY(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {
         if (!e->ev_in[b]) HIP_TRY(hipEventCreateWithFlags(&e->ev_in[b], hipEventDisableTiming));
         if (!e->ev_comp[b]) HIP_TRY(hipEventCreateWithFlags(&e->ev_comp[b], hipEventDisableTiming));
         if (!e->ev_out[b]) HIP_TRY(hipEventCreateWithFlags(&e->ev_out[b], hipEventDisableTiming));
+        if (!e->ev_ori[b]) HIP_TRY(hipEventCreateWithFlags(&e->ev_ori[b], hipEventDisableTiming));
     }
     if (frames > e->ring_frames) {
         HIP_TRY(hipDeviceSynchronize());
@@ -746,10 +752,14 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
         HIP_TRY_C(hipStreamWaitEvent(e->s_in, e->ev_comp[b], 0));
         HIP_TRY_C(hipMemcpy2DAsync(e->ring_in[b], HW, host_y + (size_t)i0 * stride, stride, HW, nf, hipMemcpyHostToDevice,
                                    e->s_in));
-        if (sse)
-            HIP_TRY_C(hipMemcpy2DAsync(e->ring_ori[b], HW, host_ori + (size_t)i0 * stride, stride, HW, nf,
-                                       hipMemcpyHostToDevice, e->s_in));
         HIP_TRY_C(hipEventRecord(e->ev_in[b], e->s_in));
+        if (sse) {
+            // the originals travel on a stream of their own, so that two copy engines feed the device
+            HIP_TRY_C(hipStreamWaitEvent(e->s_ori, e->ev_comp[b], 0));
+            HIP_TRY_C(hipMemcpy2DAsync(e->ring_ori[b], HW, host_ori + (size_t)i0 * stride, stride, HW, nf,
+                                       hipMemcpyHostToDevice, e->s_ori));
+            HIP_TRY_C(hipEventRecord(e->ev_ori[b], e->s_ori));
+        }
         // compute stream: needs the frames, and the output slot drained by the copy-out of chunk k-2
         HIP_TRY_C(hipStreamWaitEvent(e->stream, e->ev_in[b], 0));
         HIP_TRY_C(hipStreamWaitEvent(e->stream, e->ev_out[b], 0));
@@ -759,15 +769,11 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
             cleanup();
             return rc;
         }
-        if (sse)
-            for (int f = 0; f < nf; ++f) {
-                if (sse_before)
-                    HIP_TRY_C(launch_sse_acc(e->ring_in[b] + (size_t)f * HW, e->ring_ori[b] + (size_t)f * HW, HW,
-                                             d_sse + i0 + f, e->stream));
-                if (sse_after)
-                    HIP_TRY_C(launch_sse_acc(e->ring_out[b] + (size_t)f * HW, e->ring_ori[b] + (size_t)f * HW, HW,
-                                             d_sse + nframes + i0 + f, e->stream));
-            }
+        if (sse) {
+            HIP_TRY_C(hipStreamWaitEvent(e->stream, e->ev_ori[b], 0));
+            HIP_TRY_C(launch_sse_clip(e->ring_in[b], e->ring_out[b], e->ring_ori[b], HW, nf, sse_before ? d_sse + i0 : nullptr,
+                                      sse_after ? d_sse + nframes + i0 : nullptr, e->stream));
+        }
         HIP_TRY_C(hipEventRecord(e->ev_comp[b], e->stream));
         // copy-out stream
         HIP_TRY_C(hipStreamWaitEvent(e->s_out, e->ev_comp[b], 0));
@@ -779,6 +785,7 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
     HIP_TRY_C(hipStreamSynchronize(e->s_out));
     HIP_TRY_C(hipStreamSynchronize(e->stream));
     HIP_TRY_C(hipStreamSynchronize(e->s_in));
+    HIP_TRY_C(hipStreamSynchronize(e->s_ori));
     if (sse) {
         std::vector<unsigned long long> h(2 * (size_t)nframes);
         HIP_TRY_C(hipMemcpy(h.data(), d_sse, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

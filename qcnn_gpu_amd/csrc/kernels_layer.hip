@@ -221,6 +221,47 @@ hipError_t launch_sse_acc(const void *a, const void *b, size_t n, unsigned long 
     return hipGetLastError();
 }
 
+// Both sums of a clip chunk in one launch: frame f = blockIdx.y; sum_before[f] += |in_f - ori_f|^2 and
+// sum_after[f] += |out_f - ori_f|^2 (either sum array may be null).  Frames are n bytes apart in all three.
+__global__ __launch_bounds__(256) void k_sse_clip(const uint8_t *__restrict__ in, const uint8_t *__restrict__ out,
+                                                  const uint8_t *__restrict__ ori, size_t n, unsigned long long *sum_before,
+                                                  unsigned long long *sum_after)
+{
+    const size_t f = blockIdx.y;
+    const uint8_t *a = in + f * n, *c = out + f * n, *o = ori + f * n;
+    unsigned long long sb = 0, sa = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int ov = (int)o[i];
+        const int d0 = (int)a[i] - ov, d1 = (int)c[i] - ov;
+        sb += (unsigned)(d0 * d0);
+        sa += (unsigned)(d1 * d1);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sb += __shfl_down(sb, off, 64);
+        sa += __shfl_down(sa, off, 64);
+    }
+    __shared__ unsigned long long part[2][4];
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = sb;
+        part[1][threadIdx.x >> 6] = sa;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sum_before) atomicAdd(sum_before + f, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        if (sum_after) atomicAdd(sum_after + f, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    }
+}
+
+hipError_t launch_sse_clip(const void *in, const void *out, const void *ori, size_t n, int nframes,
+                           unsigned long long *sum_before, unsigned long long *sum_after, hipStream_t s)
+{
+    if (n == 0 || nframes < 1) return hipSuccess;
+    const int gx = (int)((n + 255) / 256 < 128 ? (n + 255) / 256 : 128);
+    hipLaunchKernelGGL(k_sse_clip, dim3(gx, nframes), dim3(256), 0, s, (const uint8_t *)in, (const uint8_t *)out,
+                       (const uint8_t *)ori, n, sum_before, sum_after);
+    return hipGetLastError();
+}
+
 // [H][W][48] internal channel order -> Conc1.conc layout [12][H][W][4] (test/tap helper).
 __global__ __launch_bounds__(256) void k_conc_to_ref(const int8_t *__restrict__ in, int8_t *__restrict__ out,
                                                      size_t hw)

@@ -173,6 +173,8 @@ hipError_t launch_apply_res_y(const void *x, void *rec, const void *res, int mul
                               hipStream_t s);
 hipError_t launch_sse(const void *a, const void *b, size_t n, unsigned long long *dev_sum, hipStream_t s);
 hipError_t launch_sse_acc(const void *a, const void *b, size_t n, unsigned long long *dev_sum, hipStream_t s);
+hipError_t launch_sse_clip(const void *in, const void *out, const void *ori, size_t n, int nframes,
+                           unsigned long long *sum_before, unsigned long long *sum_after, hipStream_t s);
 hipError_t launch_conc_to_ref(const void *conc_internal, void *conc_ref, int H, int W, hipStream_t s);
 hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s);
 hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s);
