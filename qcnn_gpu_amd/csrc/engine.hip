@@ -129,14 +129,16 @@ static int ensure_float(qcnn_engine *e)
 {
     if (e->float_ready) return QCNN_OK;
     HIP_TRY(hipSetDevice(e->gpu));
-    HIP_TRY(hipMalloc(&e->f_xp, sizeof(float) * e->HW));
-    HIP_TRY(hipMalloc(&e->f_u1, sizeof(float) * 64 * e->HW));
-    HIP_TRY(hipMalloc(&e->f_conc1, sizeof(float) * 48 * e->HW));
-    HIP_TRY(hipMalloc(&e->f_conc2, sizeof(float) * 48 * e->HW));
-    HIP_TRY(hipMalloc(&e->f_u4, sizeof(float) * e->HW));
+    // a buffer that exists is kept, so a call repeated after a failed allocation leaks nothing
+    auto need = [&](float **p, size_t floats) -> hipError_t { return *p ? hipSuccess : hipMalloc(p, sizeof(float) * floats); };
+    HIP_TRY(need(&e->f_xp, e->HW));
+    HIP_TRY(need(&e->f_u1, 64 * e->HW));
+    HIP_TRY(need(&e->f_conc1, 48 * e->HW));
+    HIP_TRY(need(&e->f_conc2, 48 * e->HW));
+    HIP_TRY(need(&e->f_u4, e->HW));
     for (int l = 0; l < 6; ++l) {
-        HIP_TRY(hipMalloc(&e->f_w[l], sizeof(float) * fwsize(l)));
-        HIP_TRY(hipMalloc(&e->f_b[l], sizeof(float) * L_COUT[l]));
+        HIP_TRY(need(&e->f_w[l], fwsize(l)));
+        HIP_TRY(need(&e->f_b[l], L_COUT[l]));
     }
     e->float_ready = true;
     return QCNN_OK;
