@@ -4,15 +4,25 @@
     python bench.py --gpus N --steps K --warmup W
 
 One step = one pass of forward_blu over one batch of synthetic Y frames that are already resident
-in HBM (default: 16 frames of 1920x1080, QP37 model: BASELINE.json configs[1]).  With N > 1 the
-script is launched once per GPU by torch.distributed.run; frames are sharded across ranks with no
-data-path collective (weak scaling), and the only communication is the barrier / max-reduction that
-brackets the timed region.  Rank 0 prints ONE JSON line.
+in HBM (default: 512 frames of 1920x1080 per GPU, QP37 model: BASELINE.json configs[1]; the fused
+kernels walk them 16 frames per launch).  The batch is that large so that K = 20 steps keep the
+device busy for about a second: shorter bursts ride the boost clock and overstate the sustained
+rate.  Before the W warm-up steps the loop runs untimed until the device has been busy for
+--prewarm seconds (clock ramp).
+
+With N > 1 frames are sharded across one process per GPU with no data-path collective (weak
+scaling); the only communication is the barrier / max-reduction that brackets the timed region.
+Started plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script launches
+its N ranks itself through torch.distributed.run, before anything touches the GPU; started by
+torch.distributed.run it is one rank.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,10 +31,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from qcnn_gpu_amd import capi, quant_tables, synth  # noqa: E402
-from qcnn_gpu_amd.formats import LAYERS, MACS_PER_PIXEL  # noqa: E402
-from qcnn_gpu_amd.qvrcnn import qvrcnn  # noqa: E402
-
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA peak of MI355X: 2x the ~2.5 PFLOP/s bf16 dense figure
 PEAK_HBM_GBS = 8000.0
 
@@ -32,45 +38,89 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--qp", type=int, default=37)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0: about 1 GiB of frames, 512 at 1080p)")
     ap.add_argument("--group", type=int, default=0, help="frames per kernel launch (0 = engine default)")
+    ap.add_argument("--prewarm", type=float, default=2.0, help="seconds of untimed launches before the warm-up steps")
+    ap.add_argument("--exact", action="store_true",
+                    help="force the float-pipeline kernels (what a model that fails the integer-path proof runs on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-shared-gpus", action="store_true",
+                    help="let ranks share a device when fewer than --gpus are present (rehearsal only)")
     ap.add_argument("--e2e", action="store_true", help="also time the PCIe-inclusive loop of inference/kernel.cu:89-101")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run job.
+    Nothing in this process has touched the GPU yet, and it only waits for the child."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
 
 
 def cpu_baseline(qp, h, w):
     """float32 restatement of training/model.py (model_blu) on the host cores, bounded sample."""
     import torch
     from oracle import float_model
+    from qcnn_gpu_amd import quant_tables, synth
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
-    torch.set_num_threads(cores)
     m = synth.synth_model(qp)
     _, anc = synth.synth_frames(h, w, qp)
     ws, bs, blu = float_model.dequantise(m, quant_tables.QUANT_ROWS[qp])
+    torch.set_num_threads(cores)
     float_model.forward_float(ws, bs, blu, anc[0][:64, :64].copy())     # warm-up (configs[0] shape)
     t0 = time.perf_counter()
     float_model.forward_float(ws, bs, blu, anc[0])
     first = time.perf_counter() - t0
-    reps = max(1, min(30, int(12.0 / max(first, 1e-3))))   # about 12 s of CPU work
+    reps = max(1, min(30, int(10.0 / max(first, 1e-3))))   # about 10 s of CPU work on all cores
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
         float_model.forward_float(ws, bs, blu, anc[0])
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
+    # one thread: a quarter-height band of the same frame, once (a few seconds)
+    band = np.ascontiguousarray(anc[0][: max(h // 4, min(h, 64))])
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    float_model.forward_float(ws, bs, blu, band)
+    one = time.perf_counter() - t0
+    torch.set_num_threads(cores)
     return {"value": round(h * w / med / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x one {w}x{h} Y frame, float32 torch-CPU restatement of training/model.py model_blu, "
-                      f"median {med:.3f} s/frame"}
+            "value_1_thread": round(band.size / one / 1e6, 3), "cpu": cpu_model(), "torch": torch.__version__,
+            "sample": f"{reps} x one {w}x{h} Y frame on {cores} threads, float32 torch-CPU restatement of training/model.py "
+                      f"model_blu, median {med:.3f} s/frame; 1 thread: one {band.shape[1]}x{band.shape[0]} band of it, {one:.2f} s"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+
+    from qcnn_gpu_amd import capi, synth
+    from qcnn_gpu_amd.formats import LAYERS, MACS_PER_PIXEL
+    from qcnn_gpu_amd.qvrcnn import qvrcnn
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,21 +142,29 @@ def main():
     lib = capi.load()
     ndev = C.c_int()
     capi.check(lib.qcnn_device_count(C.byref(ndev)))
+    if ndev.value < world and not a.allow_shared_gpus:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev.value} GPU(s) present "
+                         "(--allow-shared-gpus lets ranks share a device for a rehearsal)")
     dev = local_rank % max(ndev.value, 1)
 
-    h, w, qp, B = a.height, a.width, a.qp, a.batch
+    h, w, qp = a.height, a.width, a.qp
     hw = h * w
-    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
-    # distinct frames per rank and per slot: rank r owns frames r*B .. r*B+B-1 of the synthetic clip
-    _, anc = synth.synth_frames(h, w, qp, frames=min(B, 4), seed=0x51434E4E + rank)
+    B = a.batch if a.batch > 0 else max(16, ((1 << 30) // hw) // 16 * 16)
+    m = synth.synth_model(qp)
+    mb = m.to_nchw_vect_c_bytes()
+    # distinct frames per rank: rank r cycles through its own four synthetic frames
+    nsrc = min(B, 4)
+    _, anc = synth.synth_frames(h, w, qp, frames=nsrc, seed=0x51434E4E + rank)
     net = qvrcnn(dev, 1, 1, h, w)
+    if a.exact:
+        net.set_exact(True)
     net.load_static_para(mb)
     fpl = min(net.batch_group(a.group), B)      # frames one launch of each fused kernel covers
     d_in, d_out = C.c_void_p(), C.c_void_p()
     capi.check(lib.qcnn_dev_alloc(C.byref(d_in), B * hw))
     capi.check(lib.qcnn_dev_alloc(C.byref(d_out), B * hw))
     for i in range(B):
-        f = np.ascontiguousarray(anc[i % anc.shape[0]])
+        f = np.ascontiguousarray(anc[i % nsrc])
         capi.check(lib.qcnn_dev_h2d(C.c_void_p(d_in.value + i * hw), f.ctypes.data, hw))
 
     def step():
@@ -117,11 +175,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # clock ramp: untimed launches until the device has been busy for --prewarm seconds
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < a.prewarm:
+        net.forward_blu_batch(d_in.value, d_out.value, min(B, 4 * fpl), hw)
+        capi.check(lib.qcnn_dev_sync())
     for _ in range(a.warmup):
         step()
     barrier()
-    net.set_timing(True)
-    net.kernel_times_us(reset=True)
+    # ---- timed region: exactly --steps steps, no timing events on the stream ----
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -133,21 +195,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
         elapsed = float(t.item())
+    # ---- per-kernel launch times: HIP events on the engine stream, in an untimed pass of their own ----
+    net.set_timing(True)
+    net.kernel_times_us(reset=True)
+    for _ in range(max(1, min(a.steps, 4))):
+        step()
     ka_us, kb_us, passes = net.kernel_times_us(reset=True)
     net.set_timing(False)
 
-    # the timed output must be the real thing: check frame 0 of the last step against the oracle
-    # on rank 0 (outside the timed region; bounded: one 64-row band at full width)
+    # the timed output must be the real thing: the first and the last frame of the batch, whole, against the
+    # oracle on rank 0 (outside the timed region)
     parity = None
     e2e = None
     if rank == 0:
         from oracle import c_oracle
+        parity = True
         rec = np.empty((h, w), np.uint8)
+        for i in sorted({0, B - 1}):
+            capi.check(lib.qcnn_dev_d2h(rec.ctypes.data, C.c_void_p(d_out.value + i * hw), hw))
+            rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i % nsrc]))
+            parity = parity and bool(np.array_equal(rec, rec_o))
         capi.check(lib.qcnn_dev_d2h(rec.ctypes.data, d_out, hw))
-        band = min(h, 96)
-        rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[0][:band]))
-        keep = band - 6 if band < h else band                # rows whose 13x13 support lies inside the band
-        parity = bool(np.array_equal(rec[:keep], rec_o[:keep]))
         if a.e2e:
             host_in = np.ascontiguousarray(anc[0])
             host_out = np.empty_like(host_in)
@@ -170,12 +238,12 @@ def main():
             clip = np.ctypeslib.as_array(C.cast(p_in, C.POINTER(C.c_uint8)), shape=(nclip, h, w))
             rec_clip = np.ctypeslib.as_array(C.cast(p_out, C.POINTER(C.c_uint8)), shape=(nclip, h, w))
             for i in range(nclip):
-                clip[i] = anc[i % anc.shape[0]]
+                clip[i] = anc[i % nsrc]
             capi.check(lib.qcnn_forward_blu_clip(net._h, p_in, p_out, 16, hw, None, None, None))
             t1 = time.perf_counter()
             capi.check(lib.qcnn_forward_blu_clip(net._h, p_in, p_out, nclip, hw, None, None, None))
             e2e_clip = nclip * hw / (time.perf_counter() - t1) / 1e6
-            parity = parity and bool(np.array_equal(rec_clip[0], rec)) and bool(np.array_equal(rec_clip[nclip - 4], rec))
+            parity = parity and bool(np.array_equal(rec_clip[0], rec)) and bool(np.array_equal(rec_clip[nclip - nsrc], rec))
             capi.check(lib.qcnn_host_free_pinned(p_in))
             capi.check(lib.qcnn_host_free_pinned(p_out))
 
@@ -205,24 +273,32 @@ def main():
                                        "over their summed launch time; the conc1 hand-off between the two kernels is what moves"}
             except Exception:
                 traffic = None
+        shape_tag = {(1080, 1920, 37): "configs[1]", (2160, 3840, 32): "configs[3] shape"}.get((h, w, qp), "custom")
         out = {
             "metric": "Mpixels/s, forward_blu on 1920x1080 Y frames, QP37 int8 QVRCNN" if (h, w, qp) == (1080, 1920, 37)
                       else f"Mpixels/s, forward_blu on {w}x{h} Y frames, QP{qp} int8 QVRCNN",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {w}x{h} Y frame, QP{qp} int8, frames resident in HBM",
-                       "frames_per_step_per_gpu": B, "frames_per_launch": fpl, "frame": [h, w], "qp": qp, "sharding": f"frames over {world} GPU(s), no collective"},
+            "config": {"workload": f"{shape_tag}: {w}x{h} Y frame, QP{qp} int8, frames resident in HBM",
+                       "frames_per_step_per_gpu": B, "frames_per_launch": fpl, "frame": [h, w], "qp": qp,
+                       "epilogue": "float pipeline (EXACT)" if net.is_exact else "integer (proved at load)",
+                       "devices_present": ndev.value, "prewarm_s": a.prewarm,
+                       "sharding": f"frames over {world} GPU(s), no collective"},
             "roofline": {"bound": "mfma", "kernel": "k_c1c2 (I1.ppro + C1 + C2_1 + C2_2 + concat)",
-                         "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TFLOP/s",
+                         "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                          "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic,
                          "note": "int8 ops (2 per MAC); algorithmic 91 264 ops/pixel for this kernel x %d pixels per launch "
-                                 "(%d frames); avg launch %.1f us (k_c3c4: %.1f us) over %d launches, HIP events on the engine stream"
+                                 "(%d frames); avg launch %.1f us (k_c3c4: %.1f us) over %d launches, HIP events on the engine "
+                                 "stream in an untimed pass after the timed region"
                                  % (hw * fpl, fpl, ka_us, kb_us, passes),
                          "whole_pass_frac": round((2.0 * MACS_PER_PIXEL * hw * fpl / ((ka_us + kb_us) * 1e-6) / 1e12) / PEAK_INT8_TOPS, 4)
-                                            if ka_us + kb_us > 0 else None},
+                                            if ka_us + kb_us > 0 else None,
+                         "whole_pass_frac_wall": round(2.0 * MACS_PER_PIXEL * value * 1e6 / world / 1e12 / PEAK_INT8_TOPS, 4)},
             "parity_vs_oracle": parity,
         }
+        if ndev.value < world:
+            out["config"]["note"] = f"{world} ranks share {ndev.value} device(s): a rehearsal, not a scaling measurement"
         if hbm is not None:
             out["roofline"]["hbm"] = hbm
         if e2e is not None:

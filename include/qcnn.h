@@ -81,8 +81,10 @@ int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nfra
  * `nframes` frames load_data (H2D), forward_blu, D2H of I1.x_rec.  Frame i is read from
  * host_y + i*stride and written to host_rec + i*stride (stride in bytes, >= height*width).  Runs as
  * a three-stream pipeline over groups of frames (see qcnn_batch_group): the H2D copy of group k+1 and
- * the D2H copy of group k-1 overlap the kernels of group k; the caller's buffers are page-locked for
- * the duration of the call when the runtime allows it.  Blocking: returns when host_rec is complete.
+ * the D2H copy of group k-1 overlap the kernels of group k when the caller's buffers are page-locked
+ * (qcnn_host_alloc_pinned, or qcnn_host_register on memory the caller owns); pageable buffers work too, through
+ * the runtime's staging copies.  The call itself registers nothing: sharded callers hand overlapping spans of
+ * one clip to several engines.  Blocking: returns when host_rec is complete.
  * If host_ori is not NULL (same stride), sse_before[i] / sse_after[i] (either may be NULL) receive the
  * integer sums of squared differences of frame i against the original before and after the net,
  * computed on the device: the numerators of vrcnn_data::psnr / psnr_pf (inference/yuv_data.cpp:87-112). */
@@ -320,6 +322,10 @@ int qcnn_dev_memset(void *dev, int value, size_t bytes);
 int qcnn_dev_sync(void);
 int qcnn_host_alloc_pinned(void **host, size_t bytes);
 int qcnn_host_free_pinned(void *host);
+/* Page-locks / releases `bytes` of memory the caller owns (hipHostRegister / hipHostUnregister), e.g. the three
+ * clips of vrcnn_data (inference/yuv_data.cpp:8-10) when they were allocated with new[]. */
+int qcnn_host_register(void *host, size_t bytes);
+int qcnn_host_unregister(void *host);
 
 /* ---- offline model conversion (host only) ----------------------------------------------- */
 /* HWCN2NCHW_VECT_C_CPU, inference/mat.cu:97-119: out[n][c/4][h][w][c%4] = in[h][w][c][n]. */

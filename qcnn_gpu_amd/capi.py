@@ -21,6 +21,7 @@ SYMBOLS = (
     "qcnn_stream", "qcnn_set_timing", "qcnn_kernel_times_us", "qcnn_op_ppro", "qcnn_op_conv_static",
     "qcnn_op_quant_blu", "qcnn_op_apply_res_y", "qcnn_set_device", "qcnn_dev_alloc", "qcnn_dev_free", "qcnn_dev_h2d",
     "qcnn_dev_d2h", "qcnn_dev_memset", "qcnn_dev_sync", "qcnn_host_alloc_pinned", "qcnn_host_free_pinned",
+    "qcnn_host_register", "qcnn_host_unregister",
     "qcnn_hwcn2nchw_vect_c", "qcnn_model_qfp_hwcn2nchw_vect_c",
     # dynamic-quantisation path
     "qcnn_load_para", "qcnn_load_para_mem", "qcnn_forward", "qcnn_forward_layered", "qcnn_dynamic_state", "qcnn_op_activate",
@@ -113,6 +114,8 @@ def load():
     L.qcnn_dev_memset.argtypes = [vp, i, sz]
     L.qcnn_host_alloc_pinned.argtypes = [C.POINTER(vp), sz]
     L.qcnn_host_free_pinned.argtypes = [vp]
+    L.qcnn_host_register.argtypes = [vp, sz]
+    L.qcnn_host_unregister.argtypes = [vp]
     L.qcnn_hwcn2nchw_vect_c.restype = C.c_long
     L.qcnn_hwcn2nchw_vect_c.argtypes = [vp, i, i, i, i, vp]
     L.qcnn_model_qfp_hwcn2nchw_vect_c.argtypes = [C.c_char_p, C.c_char_p, i]

@@ -91,6 +91,8 @@ struct qcnn_engine {
     hipEvent_t ev_ori[2] = {nullptr, nullptr};
     uint8_t *ring_in[2] = {nullptr, nullptr}, *ring_out[2] = {nullptr, nullptr}, *ring_ori[2] = {nullptr, nullptr};
     int ring_frames = 0;  // capacity of each ring slot, in frames
+    unsigned long long *clip_sse = nullptr;  // [2][clip_sse_frames]: per-frame sums before / after the net
+    int clip_sse_frames = 0;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
@@ -104,11 +106,13 @@ static int ensure_layered(qcnn_engine *e)
 {
     if (e->layered_ready) return QCNN_OK;
     HIP_TRY(hipSetDevice(e->gpu));
-    HIP_TRY(hipMalloc(&e->x_ppro, 4 * e->HW));
-    for (int l = 0; l < 6; ++l) HIP_TRY(hipMalloc(&e->u[l], sizeof(float) * L_COUT[l] * e->HW));
-    HIP_TRY(hipMalloc(&e->v1, 64 * e->HW));
-    HIP_TRY(hipMalloc(&e->conc1, 48 * e->HW));
-    HIP_TRY(hipMalloc(&e->conc2, 48 * e->HW));
+    // a buffer that exists is kept, so a call repeated after a failed allocation leaks nothing
+    auto need = [&](auto **p, size_t bytes) -> hipError_t { return *p ? hipSuccess : hipMalloc(p, bytes); };
+    HIP_TRY(need(&e->x_ppro, 4 * e->HW));
+    for (int l = 0; l < 6; ++l) HIP_TRY(need(&e->u[l], sizeof(float) * L_COUT[l] * e->HW));
+    HIP_TRY(need(&e->v1, 64 * e->HW));
+    HIP_TRY(need(&e->conc1, 48 * e->HW));
+    HIP_TRY(need(&e->conc2, 48 * e->HW));
     e->layered_ready = true;
     return QCNN_OK;
 }
@@ -254,43 +258,60 @@ static void pack_fragments(const LayerView L[6], std::vector<int8_t> &out)
         }
 }
 
+// Range of the accumulator of output channel k of layer l over every possible input: the inputs of C1 are
+// x - 128 in [-128, 127], those of the other layers are requantised activations in [0, 127], so the positive
+// and the negative weights bound the sum separately (about half of what sum|w| * 127 would allow).
+static void acc_range(const LayerView &L, int l, int k, long long *lo, long long *hi)
+{
+    long long pos = 0, neg = 0;  // sum of the positive weights, sum of |negative weights|
+    for (int c = 0; c < L.cin; ++c)
+        for (int r = 0; r < L.ks; ++r)
+            for (int s = 0; s < L.ks; ++s) {
+                const int w = L.at(k, c, r, s);
+                if (w > 0) pos += w;
+                else neg -= w;
+            }
+    const long long in_lo = l == 0 ? -128 : 0, in_hi = 127;
+    *hi = pos * in_hi - neg * in_lo;
+    *lo = pos * in_lo - neg * in_hi;
+}
+
 // Decides whether the integer fast path reproduces the reference's float32 pipeline for THIS
-// model.  With every |acc|, |bias| and |acc + bias| (+ the requantiser's rounding offset, which the
-// integer path adds to the bias) below 2^23 all float operations are exact and the sum is a signed
-// 24-bit operand of the requantiser's multiply; with requant(blu) == 127 the clip-to-127 arm
-// equals requantising min(u, blu), and the saturating 32-bit product (see requant4_int) keeps
-// byte 3 at 127 beyond it.
+// model.  With every |acc| and |bias| at most 2^24 the conversions to float are exact, and with
+// s = acc + bias + rounding offset of the requantiser (which the integer path adds to the bias) inside
+// [-2^23, 2^23) the float sum is exact too and s is a signed 24-bit operand of the requantiser's
+// multiply; with requant(blu) == 127 the clip-to-127 arm equals requantising min(u, blu), and the
+// saturating 32-bit product (see requant4_int) keeps byte 3 at 127 beyond it.
 static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
 {
+    const long long LIM24 = 1ll << 24, LIM23 = 1ll << 23;
     for (int l = 0; l < 5; ++l) {
         const Requant &q = rq[l];
         if (q.blu < 0 || q.mul <= 0 || q.shift > 24 || q.bias < 0) return false;
-        const int in_max = l == 0 ? 128 : 127;  // C1 input is x-128 in [-128,127]; others are in [0,127]
         for (int k = 0; k < L[l].cout; ++k) {
-            long long sum = 0;
-            for (int c = 0; c < L[l].cin; ++c)
-                for (int r = 0; r < L[l].ks; ++r)
-                    for (int s = 0; s < L[l].ks; ++s) sum += std::abs(L[l].at(k, c, r, s));
-            const long long b = std::llabs((long long)L[l].b[k]);
-            if (sum * in_max + b + q.bias >= (1ll << 23)) return false;
+            long long lo, hi;
+            acc_range(L[l], l, k, &lo, &hi);
+            const long long b = L[l].b[k];
+            if (-lo > LIM24 || hi > LIM24 || std::llabs(b) > LIM24) return false;
+            if (lo + b + q.bias < -LIM23 || hi + b + q.bias >= LIM23) return false;
         }
-        if ((long long)q.blu + q.bias >= (1ll << 23)) return false;
+        if ((long long)q.blu + q.bias >= LIM23) return false;
         const long long top = ((long long)(q.blu + q.bias) * q.mul) >> q.shift;
         if (top != 127) return false;  // also bounds (blu + bias) * mulk below 128 << 24 = 2^31
         // pre-shifted multiplier: a positive signed 24-bit operand; bias * mulk <= 2^23
-        if (((long long)q.mul << (24 - q.shift)) >= (1ll << 23)) return false;
+        if (((long long)q.mul << (24 - q.shift)) >= LIM23) return false;
     }
-    // C4 + applyRes_y in integers: |acc + bias| and the multiplier are 24-bit operands, the product plus
+    // C4 + applyRes_y in integers: acc + bias and the multiplier are 24-bit operands, the product plus
     // the rounding term stays below 2^31 (so the reference's unsigned arithmetic does not wrap), and
     // pixel + residual fits the reference's short
     {
         const Requant &q = rq[5];
-        long long sum = 0;
-        for (int c = 0; c < L[5].cin; ++c)
-            for (int r = 0; r < L[5].ks; ++r)
-                for (int s = 0; s < L[5].ks; ++s) sum += std::abs(L[5].at(0, c, r, s));
-        const long long top = sum * 127 + std::llabs((long long)L[5].b[0]);
-        if (top >= (1ll << 23) || q.mul <= 0 || q.mul >= (1 << 23)) return false;
+        long long lo, hi;
+        acc_range(L[5], 5, 0, &lo, &hi);
+        const long long b = L[5].b[0];
+        if (-lo > LIM24 || hi > LIM24 || std::llabs(b) > LIM24) return false;
+        const long long top = std::max(std::llabs(lo + b), std::llabs(hi + b));
+        if (top >= LIM23 || q.mul <= 0 || q.mul >= (1 << 23)) return false;
         const long long prod = top * q.mul + (1ll << (q.shift - 1));
         if (prod >= (1ll << 31)) return false;
         if ((prod >> q.shift) + 255 >= 32767) return false;
@@ -515,6 +536,7 @@ int qcnn_destroy(qcnn_t *e)
     (void)hipFree(e->bias_i);
     (void)hipFree(e->bias_f);
     (void)hipFree(e->sse_dev);
+    (void)hipFree(e->clip_sse);
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(e->ring_in[b]);
         (void)hipFree(e->ring_out[b]);
@@ -662,7 +684,8 @@ int qcnn_batch_group(qcnn_t *e, int set, int *current)
 }
 
 // Streams, events and ring slots of the clip pipeline, created on first use / grown on demand.
-static int ensure_clip(qcnn_engine *e, int frames, bool with_ori)
+// sse_frames > 0: also the per-frame SSE buffer for a clip of that many frames.
+static int ensure_clip(qcnn_engine *e, int frames, bool with_ori, int sse_frames = 0)
 {
     HIP_TRY(hipSetDevice(e->gpu));
     if (!e->s_in) HIP_TRY(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
@@ -692,6 +715,14 @@ static int ensure_clip(qcnn_engine *e, int frames, bool with_ori)
     if (with_ori)
         for (int b = 0; b < 2; ++b)
             if (!e->ring_ori[b]) HIP_TRY(hipMalloc(&e->ring_ori[b], (size_t)e->ring_frames * e->HW));
+    if (sse_frames > e->clip_sse_frames) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(e->clip_sse);
+        e->clip_sse = nullptr;
+        e->clip_sse_frames = 0;
+        HIP_TRY(hipMalloc(&e->clip_sse, 2 * (size_t)sse_frames * sizeof(unsigned long long)));
+        e->clip_sse_frames = sse_frames;
+    }
     return QCNN_OK;
 }
 
@@ -700,7 +731,7 @@ int qcnn_clip_reserve(qcnn_t *e, int nframes, int with_sse)
     if (!e) return fail(QCNN_E_ARG, "null engine");
     if (nframes < 1) return QCNN_OK;
     const int chunk = nframes < e->group ? nframes : e->group;
-    int rc = ensure_clip(e, chunk, with_sse != 0);
+    int rc = ensure_clip(e, chunk, with_sse != 0, with_sse ? nframes : 0);
     return rc ? rc : ensure_conc(e, chunk);
 }
 
@@ -715,38 +746,24 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
     const size_t HW = e->HW;
     const int chunk = nframes < e->group ? nframes : e->group;
     const bool sse = host_ori && (sse_before || sse_after);
-    int rc = ensure_clip(e, chunk, sse);
+    int rc = ensure_clip(e, chunk, sse, sse ? nframes : 0);
     if (rc) return rc;
     rc = ensure_conc(e, chunk);
     if (rc) return rc;
-    // Page-lock the caller's buffers for the duration of the call so that the copies are true DMA and
-    // overlap the kernels.  Failure (already pinned, overlapping ranges of a sharded caller) is fine:
-    // the copies then run through the runtime's staging path.
-    const size_t span = (size_t)(nframes - 1) * stride + HW;
-    const bool reg_y = hipHostRegister(const_cast<uint8_t *>(host_y), span, hipHostRegisterDefault) == hipSuccess;
-    const bool reg_r = hipHostRegister(host_rec, span, hipHostRegisterDefault) == hipSuccess;
-    const bool reg_o = sse && hipHostRegister(const_cast<uint8_t *>(host_ori), span, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
-    unsigned long long *d_sse = nullptr;  // [2][nframes]: before, after
-    auto cleanup = [&]() {
-        if (reg_y) (void)hipHostUnregister(const_cast<uint8_t *>(host_y));
-        if (reg_r) (void)hipHostUnregister(host_rec);
-        if (reg_o) (void)hipHostUnregister(const_cast<uint8_t *>(host_ori));
-        (void)hipFree(d_sse);
-    };
+    // The caller's buffers are used as they are: page-locked memory (qcnn_host_alloc_pinned,
+    // qcnn_host_register) is copied by DMA and overlaps the kernels, pageable memory goes through the
+    // runtime's staging path.  Nothing is registered here: spans of sharded callers overlap, and a
+    // registration made by one call could be withdrawn under another call's copies.
+    unsigned long long *d_sse = e->clip_sse;  // [2][nframes]: before, after
 #define HIP_TRY_C(expr)                                                                        \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) {                                                                \
             (void)hipDeviceSynchronize();                                                      \
-            cleanup();                                                                         \
             return fail(QCNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));            \
         }                                                                                      \
     } while (0)
-    if (sse) {
-        HIP_TRY_C(hipMalloc(&d_sse, 2 * (size_t)nframes * sizeof(unsigned long long)));
-        HIP_TRY_C(hipMemsetAsync(d_sse, 0, 2 * (size_t)nframes * sizeof(unsigned long long), e->stream));
-    }
+    if (sse) HIP_TRY_C(hipMemsetAsync(d_sse, 0, 2 * (size_t)nframes * sizeof(unsigned long long), e->stream));
     for (int k = 0, i0 = 0; i0 < nframes; ++k, i0 += chunk) {
         const int b = k & 1;
         const int nf = nframes - i0 < chunk ? nframes - i0 : chunk;
@@ -768,7 +785,6 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
         rc = launch_frames(e, e->ring_in[b], e->ring_out[b], nf, HW);
         if (rc) {
             (void)hipDeviceSynchronize();
-            cleanup();
             return rc;
         }
         if (sse) {
@@ -797,7 +813,6 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
         }
     }
 #undef HIP_TRY_C
-    cleanup();
     return QCNN_OK;
 }
 
@@ -883,8 +898,10 @@ static int forward_dynamic(qcnn_engine *e, bool taps)
         if (mfma && conv_mfma_supported(L_CIN[l], L_COUT[l], L_KS[l]))
             return launch_conv_mfma(x, e->w_file[l], b, want_u ? e->u[l] : nullptr, q, mx, q ? &st->step_y[l] : nullptr,
                                     1, relu, H, W, L_CIN[l], L_COUT[l], L_KS[l], s);
+        // the direct convolution writes the float image only: the divide-quantiser follows as a pass of its own
         hipError_t he = launch_conv_static(x, e->w_file[l], b, e->u[l], H, W, L_CIN[l], L_COUT[l], L_KS[l], relu, s);
         if (he == hipSuccess && mx) he = launch_absmax(e->u[l], (size_t)L_COUT[l] * HW, mx, s);
+        if (he == hipSuccess && q) he = launch_quant_div(e->u[l], q, HW, L_COUT[l], 0, &st->step_y[l], s);
         return he;
     };
     // one layer of the trunk: branches a (and c, or -1) read `in`, their quantised outputs are concatenated in `out`
@@ -1275,10 +1292,12 @@ static int copy_steps(const int32_t *stepw, const int32_t *stepy, int n_w, int n
 {
     if (!stepw || !stepy) return fail(QCNN_E_ARG, "null argument");
     for (int k = 0; k < 4; ++k) st->stepw[k] = stepw[k], st->stepy[k] = stepy[k];
+    // the steps of a pass are positive (CovLayer::load_para rejects step_w < 1, a step_y is derived from a maximum);
+    // the device-side divisions rely on it
     for (int k = 0; k < n_w; ++k)
-        if (stepw[k] == 0) return fail(QCNN_E_ARG, "stepw[%d] is 0", k);
+        if (stepw[k] < 1) return fail(QCNN_E_ARG, "stepw[%d] = %d must be positive", k, stepw[k]);
     for (int k = 0; k < n_y; ++k)
-        if (stepy[k] == 0) return fail(QCNN_E_ARG, "stepy[%d] is 0", k);
+        if (stepy[k] < 1) return fail(QCNN_E_ARG, "stepy[%d] = %d must be positive", k, stepy[k]);
     return QCNN_OK;
 }
 
@@ -1401,6 +1420,18 @@ int qcnn_host_alloc_pinned(void **host, size_t bytes)
 int qcnn_host_free_pinned(void *host)
 {
     HIP_TRY(hipHostFree(host));
+    return QCNN_OK;
+}
+int qcnn_host_register(void *host, size_t bytes)
+{
+    if (!host) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    return QCNN_OK;
+}
+int qcnn_host_unregister(void *host)
+{
+    if (!host) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipHostUnregister(host));
     return QCNN_OK;
 }
 

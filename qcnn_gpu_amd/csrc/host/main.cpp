@@ -9,6 +9,9 @@
 //   QCNN_QPS     comma list of QPs (default "22": the loop bounds of inference/kernel.cu:122)
 //   QCNN_FRAMES  frames per sequence (default 1 = FRAME, inference/mat.cuh:23)
 //   QCNN_GPUS    number of GPUs to shard frames over (default 1; frame i -> GPU i mod G)
+//   QCNN_GPU_MAP comma list of device numbers: worker g runs on device map[g mod len] instead of device g,
+//                and QCNN_GPUS is then not limited to the devices present (e.g. QCNN_GPUS=2
+//                QCNN_GPU_MAP=0,0 runs the two-worker sharding on one GPU)
 //   QCNN_PIPELINE=1    run the timed region through qcnn_forward_blu_clip: the same H2D / forward_blu /
 //                      D2H per frame, as a three-stream pipeline over groups of frames, and the PSNR
 //                      sums on the device
@@ -61,17 +64,21 @@ static void load_model(qvrcnn &net, char *model_fn)
 }
 static void run_frame(qvrcnn &net) { float_mode() ? net.forward_float() : dynamic_mode() ? net.forward() : net.forward_blu(); }
 
+// Device of worker g: g itself, or entry g of QCNN_GPU_MAP (cyclic).
+static std::vector<int> g_gpu_map;
+static int device_of(int g) { return g_gpu_map.empty() ? g : g_gpu_map[g % g_gpu_map.size()]; }
+
 // One worker per GPU: the frame loop of inference/kernel.cu:91-97 over frames g, g+G, g+2G, ...
-static void worker(int gpu, int ngpu, char *model_fn, vrcnn_data *d, int frame, int channel, int height, int width)
+// (`net` was built and loaded before the clock started, by this worker's device)
+static void worker(int g, int ngpu, qvrcnn *net, vrcnn_data *d, int frame, int channel, int height, int width)
 {
-    qvrcnn net(gpu, 1, channel, height, width);
-    load_model(net, model_fn);
+    check(qcnn_set_device(device_of(g)));  // the current device is a per-thread setting
     const long fs = (long)channel * height * width;
-    for (int i = gpu; i < frame; i += ngpu) {
-        net.load_data(d->input + i * fs);
-        run_frame(net);
-        check(qcnn_sync(net.engine));
-        check(qcnn_dev_d2h(d->recon + i * fs, net.I1.x_rec, (size_t)fs));
+    for (int i = g; i < frame; i += ngpu) {
+        net->load_data(d->input + i * fs);
+        run_frame(*net);
+        check(qcnn_sync(net->engine));
+        check(qcnn_dev_d2h(d->recon + i * fs, net->I1.x_rec, (size_t)fs));
     }
 }
 
@@ -83,6 +90,7 @@ static void worker_clip(int gpu, int ngpu, qvrcnn *net, vrcnn_data *d, int frame
     const size_t fs = (size_t)channel * height * width;
     const int mine = frame > gpu ? (frame - gpu + ngpu - 1) / ngpu : 0;
     if (mine == 0) return;
+    check(qcnn_set_device(device_of(gpu)));
     std::vector<uint64_t> b(mine), a(mine);
     check(qcnn_forward_blu_clip(net->engine, d->input + gpu * fs, d->recon + gpu * fs, mine, fs * ngpu, d->ori + gpu * fs,
                                 b.data(), a.data()));
@@ -160,7 +168,7 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
         if (ngpu < 1) ngpu = 1;
         std::vector<qvrcnn *> nets;
         for (int g = 0; g < ngpu; ++g) {
-            nets.push_back(new qvrcnn(g, 1, channel, height, width));
+            nets.push_back(new qvrcnn(device_of(g), 1, channel, height, width));
             nets.back()->load_static_para(model_fn);
             check(qcnn_clip_reserve(nets.back()->engine, frame > g ? (frame - g + ngpu - 1) / ngpu : 0, 1));
         }
@@ -201,14 +209,20 @@ static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, 
         us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
     } else {
         // whole frames sharded round-robin, one host thread and one engine per GPU, no communication
-        // between GPUs; here the clock includes engine set-up and model load on every GPU
+        // between GPUs; engines and models are set up before the clock starts (inference/kernel.cu:86-90)
+        std::vector<qvrcnn *> nets;
+        for (int g = 0; g < ngpu; ++g) {
+            nets.push_back(new qvrcnn(device_of(g), 1, channel, height, width));
+            load_model(*nets.back(), model_fn);
+        }
         read();
         const auto t1 = std::chrono::steady_clock::now();
         std::vector<std::thread> th;
         for (int g = 0; g < ngpu; ++g)
-            th.emplace_back(worker, g, ngpu, model_fn, &test_data, frame, channel, height, width);
+            th.emplace_back(worker, g, ngpu, nets[g], &test_data, frame, channel, height, width);
         for (auto &t : th) t.join();
         us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
+        for (qvrcnn *n : nets) delete n;
     }
     report(test_data, input_fn, frame, height, width, us, nullptr, nullptr, chroma);
 }
@@ -221,7 +235,14 @@ static int run_all(char *oriname, char *inputname, int height, int width)
     int ngpu = atoi(env_or("QCNN_GPUS", "1"));
     int have = 0;
     check(qcnn_device_count(&have));
-    if (ngpu > have) ngpu = have;
+    g_gpu_map = parse_qps(env_or("QCNN_GPU_MAP", ""));
+    for (int dev : g_gpu_map)
+        if (dev < 0 || dev >= have) {
+            printf("QCNN_GPU_MAP names device %d, %d present\n", dev, have);
+            return 1;
+        }
+    if (g_gpu_map.empty() && ngpu > have) ngpu = have;
+    if (ngpu > 64) ngpu = 64;
     char input_fn[1024], model_fn[1024];
     for (int qp : qps) {
         snprintf(input_fn, sizeof input_fn, "%sQ%d.yuv", inputname, qp);  // inference/kernel.cu:124

@@ -15,6 +15,7 @@
 // The single-channel first layer (x_ppro, 4 bytes per pixel with the sample in lane 0) packs four
 // horizontally adjacent taps into one 16-byte k-group: kernel row r is covered by two k-groups
 // (columns 0..3 and 4..7, columns >= 5 with zero weights), 10 k-groups = 3 MFMA steps.
+#include <atomic>
 #include "fused_common.h"
 
 namespace qcnn {
@@ -573,30 +574,29 @@ static hipError_t conv_pair_launch(ConvPairArgs a, int ncu, hipStream_t s)
 {
     a.tiles_x = (a.W + cm::TW - 1) / cm::TW;
     a.ntiles = a.tiles_x * ((a.H + cm::TH - 1) / cm::TH);
-    static int per_cu = 0;
+    // resident workgroups per CU of this instantiation: the same on every GPU of a node, so one cached value
+    // serves all of them; atomic because one host thread per GPU may get here at the same time
+    static std::atomic<int> per_cu_cache{0};
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB, MINB>, 256, 0) != hipSuccess || n < 1)
             n = 1;
         per_cu = n;
+        per_cu_cache.store(n, std::memory_order_relaxed);
     }
     const int grid = a.ntiles < per_cu * ncu ? a.ntiles : per_cu * ncu;
     hipLaunchKernelGGL((k_conv_mfma_pair<CIN, KSA, KTA, KSB, KTB, MINB>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
+// compute units of the current device (asked every time: the threads of a multi-GPU host drive different devices)
 static int device_cus()
 {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            n > 0)
-            ncu = n;
-        else
-            ncu = 256;
-    }
-    return ncu;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        return n;
+    return 256;
 }
 
 // Branch pairs of the network: (3x3 64->32 || 5x5 64->16) and (3x3 48->16 || 1x1 48->32).
@@ -640,11 +640,13 @@ static hipError_t conv_mfma_launch_v(const ConvArgs &a0, int ncu, hipStream_t s)
     a.tiles_x = (a.W + cm::TW - 1) / cm::TW;
     a.ntiles = a.tiles_x * ((a.H + cm::TH - 1) / cm::TH);
     // persistent grid: as many workgroups as the device keeps resident (registers and LDS of this instantiation)
-    static int per_cu = 0;
+    static std::atomic<int> per_cu_cache{0};
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_mfma<KS, CIN, KT, VEC, MINB>, 256, 0) != hipSuccess || n < 1) n = 2;
         per_cu = n;
+        per_cu_cache.store(n, std::memory_order_relaxed);
     }
     const int grid = a.ntiles < per_cu * ncu ? a.ntiles : per_cu * ncu;
     hipLaunchKernelGGL((k_conv_mfma<KS, CIN, KT, VEC, MINB>), dim3(grid), dim3(256), 0, s, a);
@@ -670,15 +672,7 @@ hipError_t launch_conv_mfma(const void *x, const void *w, const void *b, void *u
                             const int *divisor_dev, int divisor, int relu, int H, int W, int cin, int cout, int ks,
                             hipStream_t s)
 {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            ncu = n;
-        else
-            ncu = 256;
-    }
+    const int ncu = device_cus();
     ConvArgs a;
     a.x = (const int8_t *)x;
     a.w = (const int8_t *)w;

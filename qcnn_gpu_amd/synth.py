@@ -140,6 +140,10 @@ def adversarial_model(kind: str) -> StaticModel:
     'wide'     : full-magnitude weights on as many taps as keep sum|w| * 127 + |b| just below 2^23, with
                  the usual clip thresholds: accumulators run from far below zero to hundreds of times
                  the threshold, which is what the integer requantiser's saturating multiply must survive.
+    'balanced' : dense weights of both signs in equal numbers, as large as keep the sum of the positive and
+                 the sum of the negative weights of a channel, times 127, below 2^23 each while sum|w| * 127
+                 passes 2^23 in C2_1 and C2_2: activations are never negative, so the accumulators stay
+                 24-bit operands although the magnitude bound alone cannot show it.
     """
     m = synth_model(37)
     if kind == "maxmag":
@@ -167,6 +171,21 @@ def adversarial_model(kind: str) -> StaticModel:
                 w[k, idx] = sgn
             lp.w = w.reshape(lp.w.shape)
             lp.b = ((np.arange(co) % 7 - 3) * 9000).astype(np.int32)
+        return m
+    if kind == "balanced":
+        for l, lp in enumerate(m.layers):
+            co = lp.w.shape[0]
+            per = lp.w[0].size
+            # per-tap magnitude: sum|w| * 127 about 1.45 * 2^23 where the layer has taps enough for it
+            base = min(127, int(1.45 * (1 << 23) / 127 / per))
+            w = np.empty((co, per), np.int64)
+            for k in range(co):
+                i = np.arange(per)
+                mag = np.maximum(base - (i + k) % 5, 1)
+                sgn = np.where((i + k) & 1, 1, -1)            # equal numbers of both signs
+                w[k] = mag * sgn
+            lp.w = w.astype(np.int8).reshape(lp.w.shape)
+            lp.b = ((np.arange(co) % 5 - 2) * 4000).astype(np.int32)
         return m
     if kind == "identity":
         for l, lp in enumerate(m.layers):

@@ -251,3 +251,63 @@ def test_driver_chroma_extension(tmp_path):
         assert np.array_equal(raw[i, h * w:h * w + q].reshape(h // 2, w // 2), rec_c[2 * i])
         assert np.array_equal(raw[i, h * w + q:].reshape(h // 2, w // 2), rec_c[2 * i + 1])
     assert (tmp_path / "recon_psnr.data").read_bytes() == struct.pack("<d", c_oracle.psnr(rec_y, ori))
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+@pytest.mark.parametrize("workers", [2, 3])
+def test_driver_multi_gpu_workers_on_one_device(tmp_path, pipeline, workers):
+    """The thread-per-GPU sharding of the driver (frame i -> worker i mod G, one engine and one host thread per
+    worker, no communication; the multi-GPU half of configs[3] / configs[4]) with QCNN_GPU_MAP folding every
+    worker onto device 0, so that it runs on a one-GPU box: reconstruction, per-frame PSNR lines,
+    recon_psnr.data and the stdout record equal the one-worker run byte for byte, and the oracle."""
+    h, w, qp, nf = 72, 120, 27, 11          # 11 frames: ragged over 2 and over 3 workers
+    ori = _write_case(tmp_path, h, w, [qp], frames=nf)
+    env = {"QCNN_QPS": str(qp), "QCNN_FRAMES": str(nf), "QCNN_PSNR_PF": "1", "QCNN_SAVE_RECON": "recon.yuv",
+           "QCNN_BATCH_GROUP": "2"}
+    if pipeline:
+        env["QCNN_PIPELINE"] = "1"
+    r1 = _run(tmp_path, h, w, env)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    single_rec = (tmp_path / "recon.yuv").read_bytes()
+    single_psnr = (tmp_path / "recon_psnr.data").read_bytes()
+    (tmp_path / "recon_psnr.data").unlink()
+    (tmp_path / "recon.yuv").unlink()
+    rN = _run(tmp_path, h, w, dict(env, QCNN_GPUS=str(workers), QCNN_GPU_MAP="0"))
+    assert rN.returncode == 0, rN.stdout + rN.stderr
+    assert (tmp_path / "recon.yuv").read_bytes() == single_rec
+    assert (tmp_path / "recon_psnr.data").read_bytes() == single_psnr
+    strip = lambda t: re.sub(r"time:\d+us", "", t)
+    assert strip(rN.stdout) == strip(r1.stdout)
+    assert rN.stdout.count("PSNR of Frame") == nf
+    anc = formats.read_yuv420_luma(str(tmp_path / f"anchor_Q{qp}.yuv"), nf, h, w)
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    rec_o = np.stack([c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i])) for i in range(nf)])
+    assert np.array_equal(formats.read_yuv420_luma(str(tmp_path / "recon.yuv"), nf, h, w), rec_o)
+    assert single_psnr == struct.pack("<d", c_oracle.psnr(rec_o, ori))
+
+
+def test_driver_gpu_map_rejects_missing_device(tmp_path):
+    _write_case(tmp_path, 32, 32, [37])
+    r = _run(tmp_path, 32, 32, {"QCNN_QPS": "37", "QCNN_GPUS": "2", "QCNN_GPU_MAP": "0,99"})
+    assert r.returncode == 1 and "QCNN_GPU_MAP names device 99" in r.stdout
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (here both on device 0) and rank 0
+    prints one JSON line with n_gpus = 2; without --allow-shared-gpus the same command refuses to run."""
+    import json
+    import sys
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "90",
+            "--width", "160", "--batch", "8", "--prewarm", "0", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(base + ["--allow-shared-gpus"], capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["parity_vs_oracle"] is True and out["scaling"] == "weak"
+    assert out["value"] > 0 and "roofline" in out
+    n = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    if n.stdout.strip() == "1":
+        r = subprocess.run(base, capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+        assert r.returncode != 0 and "only 1 GPU(s) present" in r.stderr

@@ -106,17 +106,24 @@ def test_fused_float_pipeline_variant(qp):
         _check_fused(net, y, rec_o, taps_o["conc1"])
 
 
-@pytest.mark.parametrize("kind", ["maxmag", "identity", "wide"])
+@pytest.mark.parametrize("kind", ["maxmag", "identity", "wide", "balanced"])
 def test_adversarial_models(kind):
     m = synth.adversarial_model(kind)
     mb = m.to_nchw_vect_c_bytes()
+    if kind == "balanced":
+        # sum|w| * 127 alone passes 2^23 (C2_1, C2_2), the signed sums stay below it in every layer
+        mags = [np.abs(lp.w.astype(np.int64)).reshape(lp.w.shape[0], -1).sum(1).max() * 127 for lp in m.layers]
+        pos = [np.maximum(lp.w.astype(np.int64), 0).reshape(lp.w.shape[0], -1).sum(1).max() * 127 for lp in m.layers]
+        neg = [np.maximum(-lp.w.astype(np.int64), 0).reshape(lp.w.shape[0], -1).sum(1).max() * 127 for lp in m.layers]
+        assert mags[1] >= 1 << 23 and mags[2] >= 1 << 23
+        assert max(pos[1:] + neg[1:]) + 8000 + 70 < 1 << 23
     frames = [np.zeros((21, 35), np.uint8), np.full((21, 35), 255, np.uint8), _frame(21, 35, 37)]
     with qvrcnn(0, 1, 1, 21, 35) as net:
         net.load_static_para(mb)
         if kind == "maxmag":
             assert net.is_exact               # accumulators can pass 2^24: float pipeline is selected
-        if kind == "wide":
-            assert not net.is_exact           # just inside the 24-bit operand range: integer requantiser
+        if kind in ("wide", "balanced"):
+            assert not net.is_exact           # inside the 24-bit operand range: integer requantiser
         for y in frames:
             rec_o, taps_o = _check_layered(net, mb, y)
             _check_fused(net, y, rec_o, taps_o["conc1"])

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Frames-per-launch sweep of the two fused kernels at 1080p and 4K (HIP-event launch times via bench.py).
+set -e
+out=gpurun_out/sweep
+mkdir -p $out
+for g in 1 2 4 5 8 16; do
+  timeout -k 10 120 python3 bench.py --steps 5 --warmup 2 --prewarm 1 --batch 64 --group $g --no-cpu-baseline > $out/hd_g$g.json 2> $out/hd_g$g.err
+  echo "1080p group $g done"
+done
+for g in 1 2 4 5 8 16; do
+  timeout -k 10 120 python3 bench.py --steps 5 --warmup 2 --prewarm 1 --batch 32 --group $g --height 2160 --width 3840 --qp 32 --no-cpu-baseline > $out/4k_g$g.json 2> $out/4k_g$g.err
+  echo "4K group $g done"
+done
