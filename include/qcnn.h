@@ -77,6 +77,21 @@ int qcnn_forward_blu(qcnn_t *e);
  * i*stride (stride in bytes, >= height*width).  Asynchronous on the engine stream. */
 int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride);
 
+/* qcnn_forward_blu_batch for callers that cannot allocate device memory while they run (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference,
+ * whose forward pass allocates nothing because every buffer is sized in the constructors
+ * (inference/qvrcnn.cu:4-29).  Same arguments, same results, same kernels as qcnn_forward_blu_batch; the
+ * conc1 hand-off image between the two fused kernels lives in a static device array of
+ * QCNN_NOALLOC_SCRATCH_BYTES that the library's code object carries (each GPU the library runs on holds
+ * one copy until the process ends; its address is looked up per device in qcnn_create).  The call makes
+ * no hipMalloc / hipFree and records no timing events.  A frame needs 48*height*width bytes of it:
+ * larger frames (more than QCNN_NOALLOC_SCRATCH_BYTES/48 = 2 097 152 pixels; 1920x1080 fits) are
+ * rejected with QCNN_E_UNSUPPORTED; as many frames per launch as fit are grouped.  All engines on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU (two engines, two streams) race on it
+ * and must be serialised by the caller. */
+#define QCNN_NOALLOC_SCRATCH_BYTES (96u << 20)
+int qcnn_forward_blu_batch_noalloc(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride);
+
 /* The whole timed region of inference/kernel.cu:89-101 for a clip held in HOST memory: for each of
  * `nframes` frames load_data (H2D), forward_blu, D2H of I1.x_rec.  Frame i is read from
  * host_y + i*stride and written to host_rec + i*stride (stride in bytes, >= height*width).  Runs as

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libqcnn.so")
 SYMBOLS = (
     "qcnn_last_error", "qcnn_version", "qcnn_device_count", "qcnn_create", "qcnn_destroy", "qcnn_load_static",
     "qcnn_load_static_mem", "qcnn_upload", "qcnn_upload_async", "qcnn_forward_blu", "qcnn_forward_blu_batch",
-    "qcnn_forward_blu_layered", "qcnn_batch_group", "qcnn_forward_blu_clip", "qcnn_clip_reserve",
+    "qcnn_forward_blu_batch_noalloc", "qcnn_forward_blu_layered", "qcnn_batch_group", "qcnn_forward_blu_clip", "qcnn_clip_reserve",
     "qcnn_sync", "qcnn_recon_device_ptr", "qcnn_input_device_ptr", "qcnn_bind_io", "qcnn_download",
     "qcnn_download_async", "qcnn_sse_device", "qcnn_tap_bytes", "qcnn_tap", "qcnn_tap_device_ptr",
     "qcnn_layer_params", "qcnn_layer_w_device_ptr", "qcnn_layer_b_device_ptr", "qcnn_set_exact", "qcnn_is_exact",
@@ -75,6 +75,7 @@ def load():
     L.qcnn_forward_blu.argtypes = [vp]
     L.qcnn_forward_blu_layered.argtypes = [vp]
     L.qcnn_forward_blu_batch.argtypes = [vp, vp, vp, i, sz]
+    L.qcnn_forward_blu_batch_noalloc.argtypes = [vp, vp, vp, i, sz]
     L.qcnn_batch_group.argtypes = [vp, i, C.POINTER(i)]
     L.qcnn_forward_blu_clip.argtypes = [vp, vp, vp, i, sz, vp, vp, vp]
     L.qcnn_clip_reserve.argtypes = [vp, i, i]

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,39 @@ static size_t model_bytes()
     return n;
 }
 
+// ---- scratch of qcnn_forward_blu_batch_noalloc ------------------------------------------------------
+// The conc1 hand-off image of the two fused kernels for callers that may not allocate.  The array
+// lives in the code object, so every GPU the library runs on holds its own copy at its own address
+// until the process ends.  In host code the NAME of the array is only a handle for
+// hipGetSymbolAddress: the address kernels and copies use is the per-device pointer looked up once
+// per device in scratch_of_device().
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[QCNN_NOALLOC_SCRATCH_BYTES];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static int8_t *g_scratch_ptr[SCRATCH_MAX_DEVICES];
+static hipError_t g_scratch_err[SCRATCH_MAX_DEVICES];
+static bool g_scratch_done[SCRATCH_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+// Device address of `scratch` on GPU `gpu`, which must be the current device.  The look-up runs
+// once per device (it may load the code object onto that device, which allocates; so it belongs to
+// set-up: qcnn_create calls it).  Returns null with *err set when the look-up failed.
+static int8_t *scratch_of_device(int gpu, hipError_t *err)
+{
+    if (gpu < 0 || gpu >= SCRATCH_MAX_DEVICES) {
+        if (err) *err = hipErrorInvalidDevice;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_done[gpu]) {
+        void *p = nullptr;
+        g_scratch_err[gpu] = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        g_scratch_ptr[gpu] = g_scratch_err[gpu] == hipSuccess ? static_cast<int8_t *>(p) : nullptr;
+        g_scratch_done[gpu] = true;
+    }
+    if (err) *err = g_scratch_err[gpu];
+    return g_scratch_ptr[gpu];
+}
+
 }  // namespace qcnn
 
 using namespace qcnn;
@@ -59,6 +93,8 @@ struct qcnn_engine {
     uint8_t *bound_rec = nullptr;
     // fused path
     int8_t *conc1_int = nullptr;  // [conc_frames][H][W][48]
+    int8_t *scratch_ptr = nullptr;  // this GPU's copy of the static scratch (qcnn_forward_blu_batch_noalloc), or null
+    hipError_t scratch_err = hipSuccess;
     int conc_frames = 0;          // capacity of conc1_int, in frames
     int group = 1;                // frames per kernel launch of forward_blu_batch
     int8_t *wpack = nullptr;
@@ -422,7 +458,7 @@ static int ensure_conc(qcnn_engine *e, int frames)
     return QCNN_OK;
 }
 
-static FusedArgs fused_args(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nframes, size_t stride)
+static FusedArgs fused_args(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nframes, size_t stride, int8_t *conc1)
 {
     FusedArgs a;
     a.y = y;
@@ -430,7 +466,7 @@ static FusedArgs fused_args(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int 
     a.nframes = nframes;
     a.frame_stride = stride;
     a.conc_stride = 48 * e->HW;
-    a.conc1 = e->conc1_int;
+    a.conc1 = conc1;
     a.wpack = e->wpack;
     a.bias_i = e->bias_i;
     a.bias_f = e->bias_f;
@@ -493,6 +529,8 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
         if (e_ != hipSuccess) return bail(fail(QCNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
     } while (0)
     HIP_TRY_E(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // this GPU's address of the static scratch; a failure is reported by the entry point that needs it
+    e->scratch_ptr = scratch_of_device(gpu, &e->scratch_err);
     HIP_TRY_E(hipMalloc(&e->x, e->HW));
     HIP_TRY_E(hipMalloc(&e->x_rec, e->HW));
     HIP_TRY_E(hipMalloc(&e->conc1_int, 48 * e->HW));
@@ -620,13 +658,15 @@ int qcnn_upload_async(qcnn_t *e, const uint8_t *host_y)
     return QCNN_OK;
 }
 
-// one launch of each fused kernel over `nframes` frames (nframes <= capacity of the conc1 scratch)
-static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nframes, size_t stride)
+// one launch of each fused kernel over `nframes` frames, with `conc1` (room for nframes frames) as the
+// hand-off image between them; timed = false never touches the timing events (creating one allocates)
+static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nframes, size_t stride, int8_t *conc1 = nullptr,
+                         bool timed = true)
 {
     HIP_TRY(hipSetDevice(e->gpu));
-    const FusedArgs a = fused_args(e, y, rec, nframes, stride);
+    const FusedArgs a = fused_args(e, y, rec, nframes, stride, conc1 ? conc1 : e->conc1_int);
     hipEvent_t *ev = nullptr;
-    if (e->timing) {
+    if (e->timing && timed) {
         if (e->ev_used + 3 > e->ev.size()) {
             const size_t old = e->ev.size();
             if (old < 3 * 65536) {
@@ -670,6 +710,32 @@ int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nfra
         const int nf = nframes - i < group ? nframes - i : group;
         const int rc = launch_frames(e, static_cast<const uint8_t *>(dev_y) + (size_t)i * stride,
                                      static_cast<uint8_t *>(dev_rec) + (size_t)i * stride, nf, stride);
+        if (rc) return rc;
+    }
+    return QCNN_OK;
+}
+
+int qcnn_forward_blu_batch_noalloc(qcnn_t *e, const void *dev_y, void *dev_rec, int nframes, size_t stride)
+{
+    if (!e || !dev_y || !dev_rec) return fail(QCNN_E_ARG, "null argument");
+    if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
+    if (nframes < 0 || stride < e->HW) return fail(QCNN_E_ARG, "bad batch: nframes=%d stride=%zu", nframes, stride);
+    const size_t per_frame = 48 * e->HW;
+    if (per_frame > (size_t)QCNN_NOALLOC_SCRATCH_BYTES)
+        return fail(QCNN_E_UNSUPPORTED,
+                    "a %dx%d frame needs %zu bytes of conc1 scratch, the static scratch holds %zu (at most %zu pixels per frame)",
+                    e->W, e->H, per_frame, (size_t)QCNN_NOALLOC_SCRATCH_BYTES, (size_t)QCNN_NOALLOC_SCRATCH_BYTES / 48);
+    if (!e->scratch_ptr)
+        return fail(QCNN_E_HIP, "hipGetSymbolAddress(scratch) failed on GPU %d at qcnn_create: %s", e->gpu,
+                    hipGetErrorString(e->scratch_err));
+    // frames per launch: what the static scratch holds, at most the engine's group.  Every pixel of conc1 that
+    // kernel B reads was written by kernel A of the same launch, so nothing of an earlier call needs clearing.
+    const size_t fit = (size_t)QCNN_NOALLOC_SCRATCH_BYTES / per_frame;
+    const int group = (int)std::min<size_t>(fit, (size_t)std::max(e->group, 1));
+    for (int i = 0; i < nframes; i += group) {
+        const int nf = nframes - i < group ? nframes - i : group;
+        const int rc = launch_frames(e, static_cast<const uint8_t *>(dev_y) + (size_t)i * stride,
+                                     static_cast<uint8_t *>(dev_rec) + (size_t)i * stride, nf, stride, e->scratch_ptr, false);
         if (rc) return rc;
     }
     return QCNN_OK;
