@@ -97,6 +97,7 @@ struct qcnn_engine {
     hipError_t scratch_err = hipSuccess;
     int conc_frames = 0;          // capacity of conc1_int, in frames
     int group = 1;                // frames per kernel launch of forward_blu_batch
+    bool tiled_b = false;         // QCNN_B_TILED=1: the tiled form of kernel B instead of the streaming one
     int8_t *wpack = nullptr;
     int *bias_i = nullptr;
     float *bias_f = nullptr;
@@ -292,6 +293,16 @@ static void pack_fragments(const LayerView L[6], std::vector<int8_t> &out)
             if (kb_chunk_of_kgroup(g) < 3 && rho < 3)
                 for (int j = 0; j < 16; ++j) dst[j] = (int8_t)L[5].at(0, refch_of_pos(16 * kb_chunk_of_kgroup(g) + j), rho, s);
         }
+    // C4 for the streaming kernel: one fragment, MFMA row 4s + r = tap (kernel row r, kernel column s); the B operand
+    // of lane (pixel, g) is the three dwords a lane of the C3 epilogue owns: internal positions 12g .. 12g+11, the
+    // fourth dword zero.
+    for (int lane = 0; lane < 64; ++lane) {
+        const int rho = lane & 15, g = lane >> 4;
+        const int s = rho >> 2, r = rho & 3;
+        int8_t *dst = &out[PackedOffsets::C4W9 + lane * 16];
+        if (s < 3 && r < 3)
+            for (int j = 0; j < 12; ++j) dst[j] = (int8_t)L[5].at(0, refch_of_pos(12 * g + j), r, s);
+    }
 }
 
 // Range of the accumulator of output channel k of layer l over every possible input: the inputs of C1 are
@@ -453,7 +464,11 @@ static int ensure_conc(qcnn_engine *e, int frames)
     if (e->conc1_int) HIP_TRY(hipFree(e->conc1_int));
     e->conc1_int = nullptr;
     e->conc_frames = 0;
-    HIP_TRY(hipMalloc(&e->conc1_int, (size_t)frames * 48 * e->HW));
+    const size_t bytes = (size_t)frames * conc_bytes(e->H, e->W);
+    HIP_TRY(hipMalloc(&e->conc1_int, bytes));
+    // the border stays zero: kernel A writes the frame only (cleared on the engine stream, which does not wait
+    // for the null stream)
+    HIP_TRY(hipMemsetAsync(e->conc1_int, 0, bytes, e->stream));
     e->conc_frames = frames;
     return QCNN_OK;
 }
@@ -465,7 +480,7 @@ static FusedArgs fused_args(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int 
     a.rec = rec;
     a.nframes = nframes;
     a.frame_stride = stride;
-    a.conc_stride = 48 * e->HW;
+    a.conc_stride = conc_bytes(e->H, e->W);
     a.conc1 = conc1;
     a.wpack = e->wpack;
     a.bias_i = e->bias_i;
@@ -505,7 +520,8 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     *out = nullptr;
     if (batch != 1 || channel != 1)
         return fail(QCNN_E_UNSUPPORTED, "batch=%d channel=%d: only single Y frames (1,1) are supported", batch, channel);
-    if (height < 1 || width < 1 || (long long)height * width > (1ll << 30))
+    // the conc1 image of one frame is addressed with 32-bit offsets: at most 2 GiB (about 44 million pixels)
+    if (height < 1 || width < 1 || (long long)height * width > (1ll << 30) || conc_bytes(height, width) >= (1ull << 31))
         return fail(QCNN_E_ARG, "bad frame size %dx%d", width, height);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -533,12 +549,13 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     e->scratch_ptr = scratch_of_device(gpu, &e->scratch_err);
     HIP_TRY_E(hipMalloc(&e->x, e->HW));
     HIP_TRY_E(hipMalloc(&e->x_rec, e->HW));
-    HIP_TRY_E(hipMalloc(&e->conc1_int, 48 * e->HW));
+    HIP_TRY_E(hipMalloc(&e->conc1_int, conc_bytes(height, width)));
+    HIP_TRY_E(hipMemsetAsync(e->conc1_int, 0, conc_bytes(height, width), e->stream));
     e->conc_frames = 1;
     {
         // frames per launch of the batch entry point: as many as fit a scratch budget (default 2 GiB)
         const char *gb = getenv("QCNN_BATCH_GROUP");
-        const long long fit = (2ll << 30) / (long long)(48 * e->HW);
+        const long long fit = (2ll << 30) / (long long)conc_bytes(height, width);
         e->group = gb ? atoi(gb) : (int)(fit < 1 ? 1 : fit > 16 ? 16 : fit);
         if (e->group < 1) e->group = 1;
     }
@@ -549,12 +566,20 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY_E(hipMalloc(&e->dyn, sizeof(DynState)));
     HIP_TRY_E(hipMemset(e->dyn, 0, sizeof(DynState)));
     HIP_TRY_E(hipMalloc(&e->v4, e->HW));
+#ifdef QCNN_DEBUG_CONC2
+    HIP_TRY_E(hipMalloc(&e->dbg, 48 * e->HW));
+    HIP_TRY_E(hipMemset(e->dbg, 0, 48 * e->HW));
+#endif
 #ifdef QCNN_STAMPS
     HIP_TRY_E(hipMalloc(&e->dbg, 24 * 128 * sizeof(unsigned long long)));
     HIP_TRY_E(hipMemset(e->dbg, 0, 24 * 128 * sizeof(unsigned long long)));
 #endif
     for (int l = 0; l < 6; ++l) HIP_TRY_E(hipMalloc(&e->w_file[l], wsize(l)));
 #undef HIP_TRY_E
+    {
+        const char *tb = getenv("QCNN_B_TILED");
+        e->tiled_b = tb && atoi(tb) != 0;
+    }
     const char *fx = getenv("QCNN_FORCE_EXACT");
     e->force_exact = fx && atoi(fx) != 0;
     *out = e;
@@ -682,7 +707,8 @@ static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nfr
     if (ev) HIP_TRY(hipEventRecord(ev[0], e->stream));
     HIP_TRY(launch_fused_c1c2(a, e->exact, e->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], e->stream));
-    HIP_TRY(launch_fused_c3c4(a, e->exact, e->stream));
+    if (e->tiled_b) HIP_TRY(launch_fused_c3c4(a, e->exact, e->stream));
+    else HIP_TRY(launch_fused_c3c4_stream(a, e->exact, e->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[2], e->stream));
     return QCNN_OK;
 }
@@ -720,18 +746,21 @@ int qcnn_forward_blu_batch_noalloc(qcnn_t *e, const void *dev_y, void *dev_rec, 
     if (!e || !dev_y || !dev_rec) return fail(QCNN_E_ARG, "null argument");
     if (!e->loaded) return fail(QCNN_E_STATE, "forward_blu before load_static_para");
     if (nframes < 0 || stride < e->HW) return fail(QCNN_E_ARG, "bad batch: nframes=%d stride=%zu", nframes, stride);
-    const size_t per_frame = 48 * e->HW;
+    const size_t per_frame = conc_bytes(e->H, e->W);  // 48 bytes per pixel of the frame and of its zero border
     if (per_frame > (size_t)QCNN_NOALLOC_SCRATCH_BYTES)
-        return fail(QCNN_E_UNSUPPORTED,
-                    "a %dx%d frame needs %zu bytes of conc1 scratch, the static scratch holds %zu (at most %zu pixels per frame)",
-                    e->W, e->H, per_frame, (size_t)QCNN_NOALLOC_SCRATCH_BYTES, (size_t)QCNN_NOALLOC_SCRATCH_BYTES / 48);
+        return fail(QCNN_E_UNSUPPORTED, "a %dx%d frame needs %zu bytes of conc1 scratch, the static scratch holds %zu", e->W, e->H,
+                    per_frame, (size_t)QCNN_NOALLOC_SCRATCH_BYTES);
     if (!e->scratch_ptr)
         return fail(QCNN_E_HIP, "hipGetSymbolAddress(scratch) failed on GPU %d at qcnn_create: %s", e->gpu,
                     hipGetErrorString(e->scratch_err));
-    // frames per launch: what the static scratch holds, at most the engine's group.  Every pixel of conc1 that
-    // kernel B reads was written by kernel A of the same launch, so nothing of an earlier call needs clearing.
+    // frames per launch: what the static scratch holds, at most the engine's group
     const size_t fit = (size_t)QCNN_NOALLOC_SCRATCH_BYTES / per_frame;
     const int group = (int)std::min<size_t>(fit, (size_t)std::max(e->group, 1));
+    // The array keeps what the last call on this GPU left in it, possibly an image of another geometry: the
+    // border of every image this call uses must read as zero, so it is cleared first (a kernel on the engine
+    // stream, ahead of kernel A; everything inside the border is written by kernel A before kernel B reads it).
+    HIP_TRY(hipSetDevice(e->gpu));
+    HIP_TRY(launch_conc_zero_border(e->scratch_ptr, std::min(group, std::max(nframes, 1)), e->H, e->W, e->stream));
     for (int i = 0; i < nframes; i += group) {
         const int nf = nframes - i < group ? nframes - i : group;
         const int rc = launch_frames(e, static_cast<const uint8_t *>(dev_y) + (size_t)i * stride,
@@ -1166,7 +1195,7 @@ static int tap_info(qcnn_t *e, int tap, void **dev, size_t *bytes)
     case QCNN_TAP_CONC1: *dev = e->conc1; *bytes = 48 * HW; return 0;
     case QCNN_TAP_CONC2: *dev = e->conc2; *bytes = 48 * HW; return 0;
     case QCNN_TAP_X_REC: *dev = e->bound_rec ? e->bound_rec : e->x_rec; *bytes = HW; return 0;
-    case QCNN_TAP_FUSED_CONC1: *dev = e->conc1_int; *bytes = 48 * HW; return 0;
+    case QCNN_TAP_FUSED_CONC1: *dev = e->conc1_int; *bytes = 48 * HW; return 0;  // size of the reference-layout copy
     case QCNN_TAP_V_C4: *dev = e->v4; *bytes = HW; return 0;
     case QCNN_TAP_F_X_PPRO: *dev = e->f_xp; *bytes = sizeof(float) * HW; return 0;
     case QCNN_TAP_F_U_C1: *dev = e->f_u1; *bytes = sizeof(float) * 64 * HW; return 0;
@@ -1274,6 +1303,16 @@ int qcnn_kernel_times_us(qcnn_t *e, double *k_c1c2_us, double *k_c3c4_us, int *p
     return QCNN_OK;
 }
 
+#ifdef QCNN_DEBUG_CONC2
+// diagnostic builds only: conc2 as the streaming kernel computed it, [H][W][48], internal channel order
+int qcnn_debug_conc2(qcnn_t *e, void *host_out)
+{
+    if (!e || !host_out) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(host_out, e->dbg, 48 * e->HW, hipMemcpyDeviceToHost));
+    return QCNN_OK;
+}
+#endif
 #ifdef QCNN_STAMPS
 // diagnostic builds only: copies the cycle stamps (24 rows x 128 slots) of the last kernels to host
 int qcnn_debug_stamps(qcnn_t *e, unsigned long long *host_out)

@@ -114,6 +114,44 @@ __device__ __forceinline__ void requant12_int(const v4i &a, const v4i &b, const 
           "s"(qab.mulk), "s"(qc.mulk));
 }
 
+// requant12_int in four pieces, one per channel index I of the three dwords, so that a caller can place
+// matrix instructions between them (two vector instructions per MFMA of the same wave issue almost for
+// free).  Piece 0 starts the dwords, the others insert their byte; LAST ends with the wait state a
+// sub-dword write needs before a vector instruction reads the register.  The accumulators must have
+// been complete for the latency of their last MFMA: inline assembly gets no hazard wait states from
+// the compiler.
+template <int I, bool LAST>
+__device__ __forceinline__ void requant12_piece(int a, int b, int c, const Requant &qab, const Requant &qc, unsigned &pa,
+                                                unsigned &pb, unsigned &pc)
+{
+    int ta, tb, tc;
+    if constexpr (I == 0) {
+        asm("v_mad_i32_i24 %3, %6, %9, 0 clamp\n\t"
+            "v_mad_i32_i24 %4, %7, %9, 0 clamp\n\t"
+            "v_mad_i32_i24 %5, %8, %10, 0 clamp\n\t"
+            "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+            "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+            "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"
+            : "=&v"(pa), "=&v"(pb), "=&v"(pc), "=&v"(ta), "=&v"(tb), "=&v"(tc)
+            : "v"(a), "v"(b), "v"(c), "s"(qab.mulk), "s"(qc.mulk));
+    } else {
+#define QCNN_REQ_PIECE(SEL, TAIL)                                                                                          \
+    asm("v_mad_i32_i24 %3, %6, %9, 0 clamp\n\t"                                                                             \
+        "v_mad_i32_i24 %4, %7, %9, 0 clamp\n\t"                                                                             \
+        "v_mad_i32_i24 %5, %8, %10, 0 clamp\n\t"                                                                            \
+        "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:" SEL " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"     \
+        "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:" SEL " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n\t"     \
+        "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:" SEL " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" TAIL     \
+        : "+v"(pa), "+v"(pb), "+v"(pc), "=&v"(ta), "=&v"(tb), "=&v"(tc)                                                    \
+        : "v"(a), "v"(b), "v"(c), "s"(qab.mulk), "s"(qc.mulk))
+        if constexpr (I == 1) QCNN_REQ_PIECE("BYTE_1", "");
+        else if constexpr (I == 2) QCNN_REQ_PIECE("BYTE_2", "");
+        else if constexpr (LAST) QCNN_REQ_PIECE("BYTE_3", "\n\ts_nop 0");
+        else QCNN_REQ_PIECE("BYTE_3", "");
+#undef QCNN_REQ_PIECE
+    }
+}
+
 // The same for the 16 channels of one 32x32 accumulator (four dwords, one requantiser).
 __device__ __forceinline__ v4i requant16_int(const v16i &d, const Requant &q)
 {

@@ -110,8 +110,9 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
                                          int x0, int y0, int H, int W)
 {
     const int gx = x0 + cb + c, gy0 = y0 + R0;
-    int8_t *out = concf + ((size_t)gy0 * W + gx) * 48 + 12 * g;  // row y sits y * W * 48 further
-    const size_t row_bytes = (size_t)W * 48;
+    // the frame sits at rows / columns 2.. of the bordered conc1 image
+    const size_t row_bytes = (size_t)conc_wp(W) * 48;  // row y sits y * row_bytes further
+    int8_t *out = concf + (size_t)(gy0 + 2) * row_bytes + (size_t)(gx + 2) * 48 + 12 * g;
     auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
         if constexpr (!EXACT) {
             requant12_int(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, d0, d1, d2);

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
             const int pi = it * 256 + mtid;
             const int row = pi / PIECES_ROW, rem = pi - row * PIECES_ROW;
             const int px = rem / 3, ch = rem - px * 3;
-            goff[it] = (row * W + px) * 48 + ch * 16;
+            goff[it] = (row * conc_wp(W) + px) * 48 + ch * 16;
             rpc[it] = row | (px << 8) | (ch << 16);
         }
         const bool last_valid = (ITER - 1) * 256 + mtid < PIECES;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
             if (tl) {
                 const int x0 = p0.tx * TW, y0 = p0.ty * TH;
                 direct = y0 >= 2 && y0 - 2 + INR <= H && x0 >= 2 && x0 - 2 + INC <= W;
-                org = a.conc1 + (size_t)p0.f * a.conc_stride + ((ptrdiff_t)(y0 - 2) * W + (x0 - 2)) * 48;
+                org = a.conc1 + (size_t)p0.f * a.conc_stride + ((ptrdiff_t)y0 * conc_wp(W) + x0) * 48;  // image (y0-2, x0-2)
             }
             auto request = [&](auto itc) {  // direct load of the 64 pieces this wave owns in group `it`
                 constexpr int it = decltype(itc)::value;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
                 for (int it = 0; it < ITER; ++it) {
                     const int gy = y0 - 2 + (rpc[it] & 0xff), gx = x0 - 2 + ((rpc[it] >> 8) & 0xff);
                     const int cy = gy < 0 ? 0 : gy >= H ? H - 1 : gy, cx = gx < 0 ? 0 : gx >= W ? W - 1 : gx;
-                    v[it] = *reinterpret_cast<const v4i *>(frame + ((size_t)cy * W + cx) * 48 + (rpc[it] >> 16) * 16);
+                    v[it] = *reinterpret_cast<const v4i *>(frame + ((size_t)(cy + 2) * conc_wp(W) + cx + 2) * 48 + (rpc[it] >> 16) * 16);
                     if (cy != gy || cx != gx) v[it] = v4i{0, 0, 0, 0};  // zero padding of C3
                 }
 #pragma unroll

@@ -1,6 +1,7 @@
 // Layer-level gfx950 kernels: one kernel per member function of the reference's layer API, on the
 // reference's own buffer layouts.  They back the qcnn_op_* entry points and the layered (tap)
 // mode; the production pass is the pair of fused kernels in kernels_fused.hip.
+#include <algorithm>
 #include "qcnn_internal.h"
 #include <stdlib.h>
 
@@ -263,24 +264,58 @@ hipError_t launch_sse_clip(const void *in, const void *out, const void *ori, siz
 }
 
 // [H][W][48] internal channel order -> Conc1.conc layout [12][H][W][4] (test/tap helper).
-__global__ __launch_bounds__(256) void k_conc_to_ref(const int8_t *__restrict__ in, int8_t *__restrict__ out,
-                                                     size_t hw)
+__global__ __launch_bounds__(256) void k_conc_to_ref(const int8_t *__restrict__ in, int8_t *__restrict__ out, int H,
+                                                     int W)
 {
-    const size_t total = hw * 48;
+    const size_t hw = (size_t)H * W, total = hw * 48;
+    const int wp = conc_wp(W);
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const size_t p = idx / 48;
         const int pos = (int)(idx - p * 48);
         const int ch = refch_of_pos(pos);
-        out[((size_t)(ch >> 2) * hw + p) * 4 + (ch & 3)] = in[idx];
+        const size_t y = p / W, x = p - y * W;
+        out[((size_t)(ch >> 2) * hw + p) * 4 + (ch & 3)] = in[((y + 2) * wp + x + 2) * 48 + pos];
     }
 }
 
+// conc_internal: the bordered [H+4+..][W+4][48] image of the fused path; conc_ref: Conc1.conc, [12][H][W][4]
 hipError_t launch_conc_to_ref(const void *conc_internal, void *conc_ref, int H, int W, hipStream_t s)
 {
-    const size_t hw = (size_t)H * W;
-    if (hw == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_conc_to_ref, dim3(4096), dim3(256), 0, s, (const int8_t *)conc_internal, (int8_t *)conc_ref,
-                       hw);
+    if ((size_t)H * W == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_conc_to_ref, dim3(4096), dim3(256), 0, s, (const int8_t *)conc_internal, (int8_t *)conc_ref, H, W);
+    return hipGetLastError();
+}
+
+// Zeroes the border of `nframes` conc1 images (rows 0, 1, H+2, H+3 and, between them, the four border pixels that
+// end one row and start the next): what kernel A leaves unwritten and kernel B reads as the zero padding of C3.
+__global__ __launch_bounds__(256) void k_conc_zero_border(int8_t *conc, int H, int W, size_t frame_bytes)
+{
+    typedef int v4 __attribute__((ext_vector_type(4)));
+    const int wp = conc_wp(W);
+    int8_t *img = conc + (size_t)blockIdx.y * frame_bytes;
+    const size_t row16 = (size_t)wp * 3;                // 16-byte pieces per row
+    const size_t full = 2 * row16 + 6;                  // rows 0, 1 and the two border pixels that start row 2
+    const size_t seams = (size_t)(H - 1) * 12;          // 4 pixels = 12 pieces after each of the rows 2 .. H
+    const size_t tail = 6 + 2 * row16;                  // the two pixels that end row H+1, then rows H+2, H+3
+    const size_t total = full + seams + tail;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t piece;
+        if (i < full) piece = i;
+        else if (i < full + seams) {
+            const size_t k = (i - full) / 12, r = (i - full) - k * 12;
+            piece = (2 + k) * row16 + (size_t)(W + 2) * 3 + r;
+        } else
+            piece = (size_t)(H + 1) * row16 + (size_t)(W + 2) * 3 + (i - full - seams);
+        reinterpret_cast<v4 *>(img)[piece] = v4{0, 0, 0, 0};
+    }
+}
+
+hipError_t launch_conc_zero_border(void *conc_internal, int nframes, int H, int W, hipStream_t s)
+{
+    if (nframes < 1) return hipSuccess;
+    const size_t total = 4 * (size_t)conc_wp(W) * 3 + 12 + (size_t)(H - 1) * 12;
+    const unsigned gx = (unsigned)std::min<size_t>((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_conc_zero_border, dim3(gx, nframes), dim3(256), 0, s, (int8_t *)conc_internal, H, W, conc_bytes(H, W));
     return hipGetLastError();
 }
 

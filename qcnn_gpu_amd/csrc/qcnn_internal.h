@@ -54,6 +54,28 @@ constexpr int LDS_BYTES = 2 * SIN_BYTES + 2 * SC3_BYTES;  // both tiles double-b
 static_assert(LDS_BYTES <= 160 * 1024, "kernel B exceeds the 160 KiB of LDS of one CU");
 }  // namespace kb
 
+// Kernel B, streaming form: every wave walks a strip of 14 output columns down a band of rows, see
+// kernels_fused_s.hip.
+namespace ks {
+constexpr int SW = 14;                        // output columns of a strip (C3 region 16, conc1 18 columns)
+constexpr int CW = SW + 4;                    // conc1 columns a strip reads (halo 2)
+constexpr int R = 6;                          // conc1 rows staged per step
+constexpr int ROW_BYTES = CW * 48;            // one conc1 row of a strip: 864 contiguous bytes of the HBM image
+constexpr int RING_BYTES = R * ROW_BYTES + 256;  // LDS of one wave: the staged group (+ slack, see kernels_fused_s.hip)
+constexpr int WAVES = 4;                      // waves per workgroup (they never synchronise)
+}  // namespace ks
+
+// The conc1 hand-off image in HBM: int8 [H + 4 + ks::R - 1][W + 4][48] per frame, the frame at rows 2..H+1,
+// columns 2..W+1, inside a border of zeros that kernel A never writes (the zero padding of C3), plus
+// ks::R - 1 rows and 1 KiB of slack that kernel B may read (and ignores) past the last row: its last
+// group of ks::R rows may start at the last border row, and a strip at the right edge runs up to 14
+// pixels into the next row.
+__host__ __device__ inline int conc_wp(int W) { return W + 4; }
+__host__ __device__ inline size_t conc_bytes(int H, int W)
+{
+    return (size_t)(H + 4 + ks::R - 1) * conc_wp(W) * 48 + 1024;
+}
+
 // Offsets (bytes) of the packed MFMA A-operand fragments inside one device buffer.
 // One fragment = 64 lanes x 16 bytes = 1 KiB, stored in lane order.
 struct PackedOffsets {
@@ -63,14 +85,15 @@ struct PackedOffsets {
     static constexpr int C3W31 = C2W21 + 18 * 1024;     // 9 fragments [s][r]
     static constexpr int C3W32 = C3W31 + 9 * 1024;      // 2 fragments [t]
     static constexpr int C4W = C3W32 + 2 * 1024;        // 3 fragments [s]
-    static constexpr int TOTAL = C4W + 3 * 1024;
+    static constexpr int C4W9 = C4W + 3 * 1024;         // 1 fragment: all nine taps as MFMA rows 4s + r
+    static constexpr int TOTAL = C4W9 + 1024;
 };
 
 // Arguments of the fused kernels (passed by value).
 struct FusedArgs {
     const uint8_t *y;        // I1.x       uint8 [H][W]
     uint8_t *rec;            // I1.x_rec   uint8 [H][W]
-    int8_t *conc1;           // [nframes][H][W][48] int8, internal channel order (see pos_of_refch())
+    int8_t *conc1;           // [nframes] images of conc_bytes(H, W), int8, internal channel order (see pos_of_refch())
     int nframes;             // frames of this launch; frame f lives at y/rec + f*frame_stride
     size_t frame_stride;     // bytes between consecutive frames of y and of rec
     size_t conc_stride;      // bytes between consecutive frames of conc1
@@ -176,8 +199,10 @@ hipError_t launch_sse_acc(const void *a, const void *b, size_t n, unsigned long 
 hipError_t launch_sse_clip(const void *in, const void *out, const void *ori, size_t n, int nframes,
                            unsigned long long *sum_before, unsigned long long *sum_after, hipStream_t s);
 hipError_t launch_conc_to_ref(const void *conc_internal, void *conc_ref, int H, int W, hipStream_t s);
+hipError_t launch_conc_zero_border(void *conc_internal, int nframes, int H, int W, hipStream_t s);
 hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s);
-hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s);
+hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s);         // tiled form (kernels_fused_b.hip)
+hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t s);  // streaming form (kernels_fused_s.hip)
 
 // float32 configuration (kernels_float.hip)
 bool conv_float_supported(int cin, int cout, int ks);
