@@ -84,7 +84,7 @@ int qcnn_forward_blu_batch(qcnn_t *e, const void *dev_y, void *dev_rec, int nfra
  * conc1 hand-off image between the two fused kernels lives in a static device array of
  * QCNN_NOALLOC_SCRATCH_BYTES that the library's code object carries (each GPU the library runs on holds
  * one copy until the process ends; its address is looked up per device in qcnn_create).  The call makes
- * no hipMalloc / hipFree and records no timing events.  A frame needs 48*(height+9)*(width+4) + 1024
+ * no hipMalloc / hipFree and records no timing events.  A frame needs 48*(height+4)*(width+4) + 1024
  * bytes of it (the image with its zero border): larger frames are rejected with QCNN_E_UNSUPPORTED
  * (1920x1080 fits, 1936x1088 does not); as many frames per launch as fit are grouped.  All engines on one GPU
  * share that GPU's array: calls that overlap in time on one GPU (two engines, two streams) race on it

@@ -359,6 +359,8 @@ static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
         if (-lo > LIM24 || hi > LIM24 || std::llabs(b) > LIM24) return false;
         const long long top = std::max(std::llabs(lo + b), std::llabs(hi + b));
         if (top >= LIM23 || q.mul <= 0 || q.mul >= (1 << 23)) return false;
+        // the streaming kernel multiplies the accumulator without its bias (the bias rides in the rounding constant)
+        if (-lo >= LIM23 || hi >= LIM23 || std::llabs(b) * q.mul + (1ll << (q.shift - 1)) >= (1ll << 31)) return false;
         const long long prod = top * q.mul + (1ll << (q.shift - 1));
         if (prod >= (1ll << 31)) return false;
         if ((prod >> q.shift) + 255 >= 32767) return false;

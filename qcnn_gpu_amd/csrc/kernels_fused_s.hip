@@ -20,6 +20,7 @@
 // MFMA and vector phases interleave as the hardware schedules them.  Zero padding: conc1 comes with a
 // border of zeros in HBM (qcnn_internal.h, conc_bytes), conc2 pixels outside the frame are zeroed in
 // registers.
+#define STAMP_ROW (wv + 8)  // diagnostic builds: rows 8..11 of the stamp buffer (kernel A owns 0..7)
 #include "fused_common.h"
 
 namespace qcnn {
@@ -35,14 +36,31 @@ __device__ __forceinline__ int lane_of_pixel(int pix, int g)
 }
 }  // namespace
 
+// Diagnostic builds only (make variant ALT=-DQCNN_ABL_...): parts of the row body switched off to see what
+// bounds it; such a build computes garbage and is never shipped.
+#if defined(QCNN_ABL_NOMFMA)
+#define MFMA3(a, b, c) (c)
+#else
+#define MFMA3(a, b, c) mfma16(a, b, c)
+#endif
+
 template <bool EXACT>
 __global__ __launch_bounds__(ks::WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_units)
 {
+#ifdef QCNN_ABL_LDS_PAD  // diagnostic builds only: fewer resident workgroups per CU
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * RING_BYTES + QCNN_ABL_LDS_PAD];
+#else
     __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * RING_BYTES];
+#endif
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int unit = blockIdx.x * WAVES + wv;
+    // Workgroups are dealt to the 8 XCDs round robin; XCD x takes the x-th eighth of the units, so that strips that
+    // share conc1 columns run on one XCD at about the same time and meet in its L2.
+    // (the grid is a multiple of 8 workgroups, so the map is one to one)
+    const int per_xcd = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int unit = wg * WAVES + wv;
     if (unit >= total_units) return;  // the waves of a workgroup never meet again: no barrier anywhere
     const int strip = unit % nstrips;
     unit /= nstrips;
@@ -91,22 +109,26 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     const int mul = a.rq[5].mul, shift = a.rq[5].shift;
 
     // staging: one wave-wide 16-byte load per conc1 row.  Lane l < 54 fetches piece l of the row's 864 bytes; the
-    // other ten lanes fetch the 160 bytes behind it (inside the image or its slack) and drop them into LDS behind
-    // the row, where the next row's pieces overwrite them (a wave's LDS writes land in order) or, after the last
-    // row, the buffer's slack takes them.
+    // other ten lanes carry an offset past the end of the buffer, for which a buffer load fetches nothing and
+    // returns zeros; they drop them into LDS behind the row, where the next row's pieces overwrite them (a wave's
+    // LDS writes land in order) or, after the last row of a group, the slack behind the group takes them.
     // conc1 row m of this band (m = 0, 1, ...) is image row ya - 2 + m = row ya + m of the bordered image; the
     // strip's first column x0 - 2 is column x0 of it.  The loads are buffer loads: a uniform descriptor of this
     // frame's image, a scalar offset per row, and lane * 16, so that no lane carries an address.
     const size_t row_bytes = (size_t)conc_wp(W) * 48;
     const __amdgpu_buffer_rsrc_t conc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t *>(a.conc1 + (size_t)f * a.conc_stride), 0, (int)a.conc_stride, 0x00020000);
-    int gstep = ya * (int)row_bytes + x0 * 48;  // byte offset of the current group inside the image
+    // rows past the border (the last group of a band at the bottom of the frame) repeat the last border row
+    int grow = ya;  // row of the bordered image the group in flight starts at
+    const int lane_off = lane < ROW_BYTES / 16 ? lane * 16 : 0x7f000000;
     auto load_row = [&](int i) {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(conc_rsrc, lane * 16, gstep + i * (int)row_bytes, 0);
+        const int row = grow + i < H + 3 ? grow + i : H + 3;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(conc_rsrc, lane_off, row * (int)row_bytes + x0 * 48, 0);
         return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
     };
+    // the wave's LDS: two groups of R rows; step t reads group t & 1 while group t + 1 is written into the other
     unsigned char *wr = ring + lane * 16;
-    const unsigned char *rd = ring + pix * 48 + gc * 16;  // + row * 864 + s * 48
+    const unsigned char *rd = ring + pix * 48 + gc * 16;  // + group * GROUP_BYTES + row * 864 + s * 48
 
     // residual input and output: lane (pixel o, lane row 0) owns output column x0 + o, o < 14
     // (addresses as a uniform frame base + a 32-bit lane offset: a frame holds at most 2^30 pixels)
@@ -121,14 +143,19 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // outside the frame skips its C4 product.
     const int cx = x0 - 1 + pix;
     const int colmask = (cx >= 0 && cx < W) ? -1 : 0;
+    const bool edge_strip = x0 == 0 || x0 + 14 >= W;  // uniform: some region column lies outside the frame
+    // applyRes_y: ((acc + bias) * mul + half) >> shift with the bias and the rounding term in one constant (the
+    // host has proved that acc, acc + bias and the whole product fit: prove_integer_path)
+    const int round4 = (1 << (shift - 1)) + b4i * mul;
 
-    // conc1 rows to walk: output row yb-1 is complete after m = yb - ya + 3
-    const int T = (yb - ya + 4 + R - 1) / R;
+    // conc1 rows to walk: conc1 row m completes conc2 row ya - 3 + m, whose C4 product completes output row
+    // ya - 4 + m, which is written while conc1 row m + 1 is processed: yb - ya + 5 rows
+    const int T = (yb - ya + 5 + R - 1) / R;
     v4i S[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) S[i] = load_row(i);
-    // residual input of output row y3 = ya - 4 + m (m = R t + j): fetched one step ahead, right after the pixel of
-    // row m - R has been used
+    // residual input of output row y3 = ya - 4 + m (slot m % R): fetched one step ahead, right after the pixel of
+    // output row y3 - R has been used
     auto yoff = [&](int y3) { return (unsigned)(y3 < 0 ? 0 : y3 >= H ? H - 1 : y3) * (unsigned)W + xcol; };
     unsigned char ypix[R];
 #pragma unroll
@@ -136,107 +163,177 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
 
     v4i acc[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
     v4i a32[2][2] = {{v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}, {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}};
-    int Pa = 0, Pb = 0;  // partial sums of output rows y2 - 1 and y2 (see below)
+    int Pa = 0, Pb = 0;            // partial sums (kernel rows) of the two output rows still open
+    v4i D4p = {0, 0, 0, 0};        // C4 product of the conc2 row completed by the previous conc1 row
 
-    for (int t = 0; t < T; ++t) {
-        const int m0 = R * t;
-        // the staged group becomes this step's LDS image; the next group and the next step's Y pixels start
-        // their way from HBM
+    // group 0 into LDS, group 1 on its way, the fragments of row 0 requested
 #pragma unroll
-        for (int i = 0; i < R; ++i) *reinterpret_cast<v4i *>(wr + i * ROW_BYTES) = S[i];  // ascending: see above
-        if (t + 1 < T) {
-            gstep += R * (int)row_bytes;
+    for (int i = 0; i < R; ++i) *reinterpret_cast<v4i *>(wr + i * ROW_BYTES) = S[i];  // ascending: see above
+    grow += R;
+#pragma unroll
+    for (int i = 0; i < R; ++i) S[i] = load_row(i);
+    v4i Bq[2][3];  // B fragments of the current conc1 row (slot row & 1) and of the next one
+#pragma unroll
+    for (int s = 0; s < 3; ++s) Bq[0][s] = *reinterpret_cast<const v4i *>(rd + s * 48);
+
+    STAMP_INIT();
+    // One conc1 row.  CHECK = false: a step whose six conc2 rows lie inside the frame and whose six output rows lie
+    // inside the band, in a strip with no column outside the frame; every test below is then known to hold.
+    auto row = [&](auto jc, auto checkc, int t) {
+        constexpr int j = decltype(jc)::value;
+        constexpr bool CHECK = decltype(checkc)::value;
+        const int m0 = R * t;
+        const unsigned char *rdc = rd + (t & 1) * GROUP_BYTES, *rdo = rd + ((t + 1) & 1) * GROUP_BYTES;
+        static_assert(R % 2 == 0 && R % 3 == 0, "the fragment and accumulator slots repeat with the step");
+        v4i(&B)[3] = Bq[j & 1];
+        v4i(&Bn)[3] = Bq[(j + 1) & 1];
+        if constexpr (j == R - 2) {
+            // group t + 1 has had four rows' time to arrive: into the other half of the LDS buffer, and group t + 2
+            // sets out
+            unsigned char *wro = wr + ((t + 1) & 1) * GROUP_BYTES;
+#pragma unroll
+            for (int i = 0; i < R; ++i) *reinterpret_cast<v4i *>(wro + i * ROW_BYTES) = S[i];
+#ifndef QCNN_ABL_NOLOAD
+            // unconditional (the last two steps fetch rows nobody reads: load_row clamps them into the image): the
+            // compiler counts only loads that are certain to be issued when it sizes the vmcnt waits of the byte
+            // loads around them, and a wait sized without these would wait for THEM
+            grow += R;
 #pragma unroll
             for (int i = 0; i < R; ++i) S[i] = load_row(i);
-        }
-        v4i B[R][3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) B[0][s] = *reinterpret_cast<const v4i *>(rd + s * 48);
-        static_for<R>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (j + 1 < R) {
-#pragma unroll
-                for (int s = 0; s < 3; ++s) B[j + 1][s] = *reinterpret_cast<const v4i *>(rd + (j + 1) * ROW_BYTES + s * 48);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // conc1 row m = m0 + j (image row y1 = ya - 2 + m) feeds conc2 rows y1 + 1 (kernel row 0: a new
-            // accumulator), y1 (kernel row 1) and y1 - 1 (kernel row 2).  Kernel row 2 goes first: it completes
-            // conc2 row y2 = y1 - 1 (C3_1 in acc[s2]; its C3_2 sits in a32[(j + 1) % 2] since the row before), whose
-            // requantisation is then threaded between the remaining matrix instructions, two of them ahead of the
-            // first piece (the accumulator must have left the matrix pipe: inline assembly gets no wait states).
-            constexpr int s0 = j % 3, s1 = (j + 2) % 3, s2 = (j + 1) % 3;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc[s2] = mfma16(f31[s][2], B[j][s], acc[s2]);
-            __builtin_amdgcn_sched_barrier(0);
-            const int y2 = ya - 3 + m0 + j;
-            const v4i c31 = acc[s2];
-            const v4i c320 = a32[(j + 1) % 2][0], c321 = a32[(j + 1) % 2][1];
-            unsigned d0, d1, d2;
-            auto other_rows = [&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                acc[s1] = mfma16(f31[s][1], B[j][s], acc[s1]);
-                acc[s0] = mfma16(f31[s][0], B[j][s], s == 0 ? b0 : acc[s0]);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            other_rows(std::integral_constant<int, 0>{});
-            if constexpr (!EXACT) requant12_piece<0, false>(c320[0], c321[0], c31[0], q32, q31, d1, d2, d0);
-            __builtin_amdgcn_sched_barrier(0);
-            other_rows(std::integral_constant<int, 1>{});
-            if constexpr (!EXACT) requant12_piece<1, false>(c320[1], c321[1], c31[1], q32, q31, d1, d2, d0);
-            __builtin_amdgcn_sched_barrier(0);
-            other_rows(std::integral_constant<int, 2>{});
-            if constexpr (!EXACT) requant12_piece<2, false>(c320[2], c321[2], c31[2], q32, q31, d1, d2, d0);
-            __builtin_amdgcn_sched_barrier(0);
-            // C3_2 of conc2 row y1 (its centre pixel): used one row later
-            a32[j % 2][0] = mfma16(f32[0], B[j][1], b1);
-            a32[j % 2][1] = mfma16(f32[1], B[j][1], b2);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!EXACT) {
-                requant12_piece<3, true>(c320[3], c321[3], c31[3], q32, q31, d1, d2, d0);
-            } else {
-                d0 = quant4<EXACT>(c31[0], c31[1], c31[2], c31[3], bf[0], bf[1], bf[2], bf[3], q31);
-                d1 = quant4<EXACT>(c320[0], c320[1], c320[2], c320[3], bf[4], bf[5], bf[6], bf[7], q32);
-                d2 = quant4<EXACT>(c321[0], c321[1], c321[2], c321[3], bf[8], bf[9], bf[10], bf[11], q32);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef QCNN_DEBUG_CONC2
-            // diagnostic build only: conc2 as this kernel sees it, [H][W][48] in the internal channel order
-            if ((unsigned)y2 < (unsigned)H && colmask && a.dbg) {
-                unsigned *dst = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(a.dbg) + ((size_t)y2 * W + cx) * 48 + 12 * g);
-                dst[0] = d0, dst[1] = d1, dst[2] = d2;
-            }
 #endif
-            // C4: lane (pixel, s) register r = w4[r][s] . conc2[y2][pixel]; conc2 row y2 is kernel row r of output
-            // row y2 - r + 1
-            v4i D4 = {0, 0, 0, 0};
-            if ((unsigned)y2 < (unsigned)H) D4 = mfma16(f4, v4i{(int)d0, (int)d1, (int)d2, 0}, v4i{0, 0, 0, 0});
-            const int P = (Pa + D4[2]) & colmask;  // output row y3 = y2 - 1: kernel rows 0, 1, 2 summed
-            Pa = Pb + D4[1];
-            Pb = D4[0];
-            const int y3 = y2 - 1;
-            if (y3 >= ya && y3 < yb) {
-                // kernel columns: out[o] = P_0[o] + P_1[o + 1] + P_2[o + 2] (lane rows 0, 1, 2)
-                const int v1 = __builtin_amdgcn_ds_bpermute(addr1, P);
-                const int v2 = __builtin_amdgcn_ds_bpermute(addr2, P);
-                const int sum = P + v1 + v2 + b4i;
-                uint8_t out;
-                if constexpr (EXACT) {
-                    const float u = (float)sum + b4;  // C4.u, inference/cnn.cu:148-155
-                    int temp = (int)u;                // applyRes_GPU_y, inference/cnn.cu:515-520
-                    temp = (int)((unsigned)temp * (unsigned)mul + (1u << (shift - 1))) >> shift;
-                    const short rec = (short)((int)ypix[j] + temp);
-                    out = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
-                } else {
-                    // the same in integers (the host has proved the operand ranges, see prove_integer_path)
-                    const int temp = (__mul24(sum, mul) + (1 << (shift - 1))) >> shift;
-                    const int rec = (int)ypix[j] + temp;
-                    out = (uint8_t)min(max(rec, 0), 255);
-                }
-                if (outlane) recf[(unsigned)y3 * (unsigned)W + (unsigned)(x0 + pix)] = out;
+        }
+        // the fragments of the next row (the first row of the other group after the last row of this one)
+        if constexpr (j + 1 < R) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) Bn[s] = *reinterpret_cast<const v4i *>(rdc + (j + 1) * ROW_BYTES + s * 48);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) Bn[s] = *reinterpret_cast<const v4i *>(rdo + s * 48);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP();
+        // conc1 row m = m0 + j (image row y1 = ya - 2 + m) feeds conc2 rows y1 + 1 (kernel row 0: a new
+        // accumulator), y1 (kernel row 1) and y1 - 1 (kernel row 2, which completes it: C3_1 of conc2 row
+        // y2 = y1 - 1 is then acc[s2]; its C3_2 sits in a32[(j + 1) % 2] since the row before).
+        //
+        // The row is a software pipeline over three conc2 rows, so that no result is waited for where it is
+        // produced: the matrix instructions of conc1 row m run next to the requantisation of conc2 row y2
+        // (four pieces, each at least two matrix instructions behind the accumulators' last write: inline
+        // assembly gets no hazard wait states from the compiler) and to the C4 epilogue of conc2 row y2 - 1,
+        // whose C4 product was issued at the end of the previous row (its gathers are issued early in this
+        // row and read late).  Successive matrix instructions never use the same accumulator.
+        constexpr int s0 = j % 3, s1 = (j + 2) % 3, s2 = (j + 1) % 3;
+        constexpr int jp = (j + R - 1) % R;  // the row before this one (its Y pixel)
+        const int y2 = ya - 3 + m0 + j;
+        acc[s2] = MFMA3(f31[0][2], B[0], acc[s2]);
+        acc[s1] = MFMA3(f31[0][1], B[0], acc[s1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // C4 of conc2 row y2 - 1 (D4p): it is kernel row r of output row y2 - 1 - r + 1; output row y3 = y2 - 2 is
+        // complete with it.  Kernel columns: out[o] = P_0[o] + P_1[o + 1] + P_2[o + 2] (lane rows 0, 1, 2).
+        int P = Pa + D4p[2];
+        if constexpr (CHECK) P &= colmask;
+        Pa = Pb + D4p[1];
+        Pb = D4p[0];
+#ifdef QCNN_ABL_NOGATHER
+        const int v1 = P, v2 = P;
+#else
+        const int v1 = __builtin_amdgcn_ds_bpermute(addr1, P);
+        const int v2 = __builtin_amdgcn_ds_bpermute(addr2, P);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        acc[s2] = MFMA3(f31[1][2], B[1], acc[s2]);
+        acc[s1] = MFMA3(f31[1][1], B[1], acc[s1]);
+        acc[s2] = MFMA3(f31[2][2], B[2], acc[s2]);
+        acc[s1] = MFMA3(f31[2][1], B[2], acc[s1]);
+        acc[s0] = MFMA3(f31[0][0], B[0], b0);
+        a32[j % 2][0] = MFMA3(f32[0], B[1], b1);  // C3_2 of conc2 row y1 (its centre pixel): used one row later
+        __builtin_amdgcn_sched_barrier(0);
+        const v4i c31 = acc[s2];
+        const v4i c320 = a32[(j + 1) % 2][0], c321 = a32[(j + 1) % 2][1];
+        unsigned d0, d1, d2;
+#ifdef QCNN_ABL_NOREQ
+        d0 = c31[0] ^ c31[1] ^ c31[2] ^ c31[3], d1 = c320[0] ^ c320[1] ^ c320[2] ^ c320[3], d2 = c321[0] ^ c321[1] ^ c321[2] ^ c321[3];
+#define REQ_PIECE(I, LAST) do { } while (0)
+#else
+#define REQ_PIECE(I, LAST) requant12_piece<I, LAST>(c320[I], c321[I], c31[I], q32, q31, d1, d2, d0)
+#endif
+        if constexpr (!EXACT) REQ_PIECE(0, false);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[s0] = MFMA3(f31[1][0], B[1], acc[s0]);
+        a32[j % 2][1] = MFMA3(f32[1], B[1], b2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!EXACT) REQ_PIECE(1, false);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[s0] = MFMA3(f31[2][0], B[2], acc[s0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!EXACT) REQ_PIECE(2, false);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP();
+        // ---- applyRes_y of output row y3 = y2 - 2
+        const int y3 = y2 - 2;
+        if (!CHECK || (y3 >= ya && y3 < yb)) {
+            const int sum = P + v1 + v2;  // C4 accumulator (its bias sits in round4)
+            uint8_t out;
+            if constexpr (EXACT) {
+                const float u = (float)sum + b4;  // C4.u, inference/cnn.cu:148-155 (b4i is 0 on this path)
+                int temp = (int)u;                // applyRes_GPU_y, inference/cnn.cu:515-520
+                temp = (int)((unsigned)temp * (unsigned)mul + (1u << (shift - 1))) >> shift;
+                const short rec = (short)((int)ypix[jp] + temp);
+                out = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
+            } else {
+                // the same in integers (the host has proved the operand ranges, see prove_integer_path)
+                const int temp = (__mul24(sum, mul) + round4) >> shift;
+                const int rec = (int)ypix[jp] + temp;
+                out = (uint8_t)min(max(rec, 0), 255);
             }
-            ypix[j] = yf[yoff(y3 + R)];
-        });
+#ifdef QCNN_ABL_NOSTORE
+            if (outlane && out == 77 && y3 == 1) recf[(unsigned)y3 * (unsigned)W + (unsigned)(x0 + pix)] = out;
+#else
+            if (outlane) recf[(unsigned)y3 * (unsigned)W + (unsigned)(x0 + pix)] = out;
+#endif
+        }
+#ifndef QCNN_ABL_NOYLOAD
+        // the residual input this slot needs one step from now (a row past the frame is never used: clamped)
+        ypix[jp] = yf[CHECK ? yoff(y3 + R) : (unsigned)(y3 + R < H ? y3 + R : H - 1) * (unsigned)W + xcol];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!EXACT) {
+            REQ_PIECE(3, true);
+        } else {
+            d0 = quant4<EXACT>(c31[0], c31[1], c31[2], c31[3], bf[0], bf[1], bf[2], bf[3], q31);
+            d1 = quant4<EXACT>(c320[0], c320[1], c320[2], c320[3], bf[4], bf[5], bf[6], bf[7], q32);
+            d2 = quant4<EXACT>(c321[0], c321[1], c321[2], c321[3], bf[8], bf[9], bf[10], bf[11], q32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef QCNN_DEBUG_CONC2
+        // diagnostic build only: conc2 as this kernel sees it, [H][W][48] in the internal channel order
+        if ((unsigned)y2 < (unsigned)H && colmask && a.dbg) {
+            unsigned *dst = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(a.dbg) + ((size_t)y2 * W + cx) * 48 + 12 * g);
+            dst[0] = d0, dst[1] = d1, dst[2] = d2;
+        }
+#endif
+        // C4 of conc2 row y2: lane (pixel, s) register r = w4[r][s] . conc2[y2][pixel]; read in the next row.
+        // A row outside the frame is the zero padding of C4.
+        if (!CHECK || (unsigned)y2 < (unsigned)H) D4p = mfma16(f4, v4i{(int)d0, (int)d1, (int)d2, 0}, v4i{0, 0, 0, 0});
+        else D4p = v4i{0, 0, 0, 0};
+        STAMP();
+    };
+    // Steps [t_lo, t_hi) need no test: their conc2 rows ya - 3 + R t .. + R - 1 lie inside the frame, their output
+    // rows ya - 5 + R t .. + R - 1 inside the band, and the strip has no column outside the frame.  Three loops
+    // rather than a test per step: two copies of the unrolled step inside one loop cost the register allocator
+    // dozens of spills.
+    int t_lo = T, t_hi = T;
+    if (!edge_strip) {
+        const int last = (H - 3 - ya < yb - 1 - ya ? H - 3 - ya : yb - 1 - ya);  // R t may be at most this
+        t_lo = ya >= 3 ? 1 : (3 - ya + R - 1) / R > 1 ? (3 - ya + R - 1) / R : 1;
+        t_hi = last >= 0 ? last / R + 1 : 0;
+        if (t_hi > T) t_hi = T;
+        if (t_lo > t_hi) t_lo = t_hi;
     }
+    int t = 0;
+    for (; t < t_lo; ++t) static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
+    for (; t < t_hi; ++t) static_for<R>([&](auto jc) { row(jc, std::false_type{}, t); });
+    for (; t < T; ++t) static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
 }
 
 hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t s)
@@ -265,7 +362,7 @@ hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t 
     const int nseg = (a.H + seg_rows - 1) / seg_rows;
     const long long units = (long long)a.nframes * nstrips * nseg;
     if (units > (1ll << 30)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((units + ks::WAVES - 1) / ks::WAVES));
+    const dim3 grid((unsigned)(((units + ks::WAVES - 1) / ks::WAVES + 7) / 8 * 8));  // a multiple of 8: see the unit map
     if (exact) hipLaunchKernelGGL(k_c3c4s<true>, grid, dim3(ks::WAVES * 64), 0, s, a, nstrips, nseg, seg_rows, (int)units);
     else hipLaunchKernelGGL(k_c3c4s<false>, grid, dim3(ks::WAVES * 64), 0, s, a, nstrips, nseg, seg_rows, (int)units);
     return hipGetLastError();

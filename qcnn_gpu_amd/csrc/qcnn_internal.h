@@ -61,20 +61,17 @@ constexpr int SW = 14;                        // output columns of a strip (C3 r
 constexpr int CW = SW + 4;                    // conc1 columns a strip reads (halo 2)
 constexpr int R = 6;                          // conc1 rows staged per step
 constexpr int ROW_BYTES = CW * 48;            // one conc1 row of a strip: 864 contiguous bytes of the HBM image
-constexpr int RING_BYTES = R * ROW_BYTES + 256;  // LDS of one wave: the staged group (+ slack, see kernels_fused_s.hip)
+constexpr int GROUP_BYTES = R * ROW_BYTES + 192;  // a staged group of R rows (+ slack, see kernels_fused_s.hip)
+constexpr int RING_BYTES = 2 * GROUP_BYTES;       // LDS of one wave: two groups
 constexpr int WAVES = 4;                      // waves per workgroup (they never synchronise)
 }  // namespace ks
 
-// The conc1 hand-off image in HBM: int8 [H + 4 + ks::R - 1][W + 4][48] per frame, the frame at rows 2..H+1,
-// columns 2..W+1, inside a border of zeros that kernel A never writes (the zero padding of C3), plus
-// ks::R - 1 rows and 1 KiB of slack that kernel B may read (and ignores) past the last row: its last
-// group of ks::R rows may start at the last border row, and a strip at the right edge runs up to 14
-// pixels into the next row.
+// The conc1 hand-off image in HBM: int8 [H + 4][W + 4][48] per frame, the frame at rows 2..H+1, columns
+// 2..W+1, inside a border of zeros that kernel A never writes (the zero padding of C3), plus 1 KiB of
+// slack that kernel B may read (and ignores) past the last row: a strip at the right edge runs up to
+// 14 pixels into the next row.
 __host__ __device__ inline int conc_wp(int W) { return W + 4; }
-__host__ __device__ inline size_t conc_bytes(int H, int W)
-{
-    return (size_t)(H + 4 + ks::R - 1) * conc_wp(W) * 48 + 1024;
-}
+__host__ __device__ inline size_t conc_bytes(int H, int W) { return (size_t)(H + 4) * conc_wp(W) * 48 + 1024; }
 
 // Offsets (bytes) of the packed MFMA A-operand fragments inside one device buffer.
 // One fragment = 64 lanes x 16 bytes = 1 KiB, stored in lane order.
