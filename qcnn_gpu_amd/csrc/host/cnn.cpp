@@ -1,4 +1,6 @@
 // Layer classes of the reference (inference/cnn.cuh) over the C ABI: host C++ only, no HIP headers.
+#include <vector>
+
 #include "cnn.h"
 
 #include <string.h>
@@ -59,28 +61,34 @@ int CovLayer::adopt(int batch, int height, int width, int inChannel, int outChan
     return 0;
 }
 
-int CovLayer::load_static_para(FILE *fp)
+// The parameter block of one layer as both model formats hold it (inference/cnn.cu:69-112): an optional leading
+// int32 (the weight step of the dynamic format), wSize int8 weights in NCHW_VECT_C order, outChannel int32 biases,
+// then `tail` more int32 (blu, mul, shift of the static format).  The biases go to the device as floats, as the
+// reference converts them (inference/cnn.cu:81,104).  Layers that adopted the engine's buffers only consume their
+// part of the file: the engine's own loader has filled those buffers.
+static void read_layer_block(CovLayer *L, FILE *fp, int *lead, int *tail, int ntail, bool upload)
 {
-    xwtype *w_h = (xwtype *)malloc(sizeof(xwtype) * (size_t)wSize);
-    btype *b_h = (btype *)malloc(sizeof(btype) * (size_t)outChannel);
-    int *b_int = (int *)malloc(sizeof(int) * (size_t)outChannel);
-    size_t ok = fread(w_h, sizeof(xwtype), (size_t)wSize, fp) == (size_t)wSize;
-    ok &= fread(b_int, sizeof(int), (size_t)outChannel, fp) == (size_t)outChannel;
-    ok &= fread(&blu, sizeof(int), 1, fp) == 1;
-    ok &= fread(&mul, sizeof(int), 1, fp) == 1;
-    ok &= fread(&shift, sizeof(int), 1, fp) == 1;
+    std::vector<xwtype> weights((size_t)L->wSize);
+    std::vector<int> bias_i((size_t)L->outChannel);
+    bool ok = !lead || fread(lead, sizeof(int), 1, fp) == 1;
+    ok = ok && fread(weights.data(), sizeof(xwtype), weights.size(), fp) == weights.size();
+    ok = ok && fread(bias_i.data(), sizeof(int), bias_i.size(), fp) == bias_i.size();
+    ok = ok && (ntail == 0 || fread(tail, sizeof(int), (size_t)ntail, fp) == (size_t)ntail);
     if (!ok) {
         printf("model file is too short.\n");
         exit(1);
     }
-    for (int i = 0; i < outChannel; i++) b_h[i] = (btype)b_int[i];  // inference/cnn.cu:104
-    if (owns_) {  // adopted layers get their parameters through the engine's own loader
-        check(qcnn_dev_h2d(w, w_h, sizeof(xwtype) * (size_t)wSize));
-        check(qcnn_dev_h2d(b, b_h, sizeof(btype) * (size_t)outChannel));
-    }
-    free(w_h);
-    free(b_h);
-    free(b_int);
+    if (!upload) return;
+    const std::vector<btype> bias_f(bias_i.begin(), bias_i.end());
+    check(qcnn_dev_h2d(L->w, weights.data(), sizeof(xwtype) * weights.size()));
+    check(qcnn_dev_h2d(L->b, bias_f.data(), sizeof(btype) * bias_f.size()));
+}
+
+int CovLayer::load_static_para(FILE *fp)
+{
+    int tail[3];
+    read_layer_block(this, fp, nullptr, tail, 3, owns_);
+    blu = tail[0], mul = tail[1], shift = tail[2];
     return 0;
 }
 
@@ -138,24 +146,7 @@ int CovLayer::viewmem(xwtype *x)
 
 int CovLayer::load_para(FILE *fp)
 {
-    xwtype *w_h = (xwtype *)malloc(sizeof(xwtype) * (size_t)wSize);
-    btype *b_h = (btype *)malloc(sizeof(btype) * (size_t)outChannel);
-    int *b_int = (int *)malloc(sizeof(int) * (size_t)outChannel);
-    size_t ok = fread(&step_w, sizeof(int), 1, fp) == 1;
-    ok &= fread(w_h, sizeof(xwtype), (size_t)wSize, fp) == (size_t)wSize;
-    ok &= fread(b_int, sizeof(int), (size_t)outChannel, fp) == (size_t)outChannel;
-    if (!ok) {
-        printf("model file is too short.\n");
-        exit(1);
-    }
-    for (int i = 0; i < outChannel; i++) b_h[i] = (btype)b_int[i];  // inference/cnn.cu:81
-    if (owns_) {  // adopted layers get their parameters through the engine's own loader
-        check(qcnn_dev_h2d(w, w_h, sizeof(xwtype) * (size_t)wSize));
-        check(qcnn_dev_h2d(b, b_h, sizeof(btype) * (size_t)outChannel));
-    }
-    free(w_h);
-    free(b_h);
-    free(b_int);
+    read_layer_block(this, fp, &step_w, nullptr, 0, owns_);
     return 0;
 }
 
@@ -239,19 +230,20 @@ int ConcatLayer::adopt(int batch_, int height_, int width_, int inChannel1_, int
 
 int ConcatLayer::concat_blu(CovLayer *C1, CovLayer *C2)
 {
-    // host bookkeeping of inference/cnn.cu:378-381 (unused by the static path, kept observable)
-    C1->step_y = ((1 << C1->shift) + C1->mul / 2) / C1->mul;
-    C2->step_y = ((1 << C2->shift) + C2->mul / 2) / C2->mul;
-    C1->max_u = 127 * C1->step_y;
-    C2->max_u = 127 * C2->step_y;
-    const size_t channelSize = (size_t)C1->height * C1->width;
-    const size_t frameSize1 = (size_t)C1->outChannel * channelSize, frameSize2 = (size_t)C2->outChannel * channelSize;
-    const size_t frameSize = frameSize1 + frameSize2;
-    for (int i = 0; i < C1->batch; i++) {
-        check(qcnn_op_quant_blu((convtype *)C1->u + i * frameSize1, (xwtype *)conc + i * frameSize, channelSize,
-                                C1->outChannel, C1->blu, C1->mul, C1->shift, nullptr));
-        check(qcnn_op_quant_blu((convtype *)C2->u + i * frameSize2, (xwtype *)conc + i * frameSize + frameSize1,
-                                channelSize, C2->outChannel, C2->blu, C2->mul, C2->shift, nullptr));
+    // Each branch is requantised with its own (blu, mul, shift) into its channel range of conc; the second range
+    // starts where the first ends, which is legal because the first branch has a multiple of 4 channels.
+    const size_t plane = (size_t)C1->height * C1->width;
+    const size_t out_frame = plane * (size_t)(C1->outChannel + C2->outChannel);
+    size_t first_channel = 0;
+    for (CovLayer *L : {C1, C2}) {
+        // host bookkeeping of inference/cnn.cu:378-381 (unused by the static path, kept observable)
+        L->step_y = ((1 << L->shift) + L->mul / 2) / L->mul;
+        L->max_u = 127 * L->step_y;
+        const size_t in_frame = plane * (size_t)L->outChannel;
+        for (int n = 0; n < C1->batch; n++)
+            check(qcnn_op_quant_blu((convtype *)L->u + n * in_frame, (xwtype *)conc + n * out_frame + first_channel * plane,
+                                    plane, L->outChannel, L->blu, L->mul, L->shift, nullptr));
+        first_channel += (size_t)L->outChannel;
     }
     return 0;
 }

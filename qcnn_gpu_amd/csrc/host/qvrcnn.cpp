@@ -209,29 +209,28 @@ int adjustOutput_static(convtype *o, xwtype *o_adj, int multiplier, int shifts, 
     return 0;
 }
 
-void qvrcnn::insert_w(int stepw, int layer)
+// Sorted insertion into the first `layer` entries of a step list (what insert_w / insert_y of
+// inference/qvrcnn.cu:305-330 maintain): entries 0 .. layer-2 are in order already, the new value goes in
+// front of the first entry it should precede and the rest move up by one.
+template <typename Before>
+static void insert_sorted(int *list, int layer, int value, Before before)
 {
-    // inference/qvrcnn.cu:305-317 (bookkeeping of the dynamic path; kept because it is host-only)
-    int i, j;
-    for (i = 0; i < layer - 1; i++)
-        if (steps.stepw[i] < stepw) {
-            for (j = layer - 1; j > i; j--) steps.stepw[j] = steps.stepw[j - 1];
-            steps.stepw[j] = stepw;
-            return;
-        }
-    steps.stepw[i] = stepw;
+    int at = 0;
+    while (at < layer - 1 && !before(value, list[at])) ++at;
+    for (int k = layer - 1; k > at; --k) list[k] = list[k - 1];
+    list[at] = value;
 }
 
+// stepw is kept in descending order ...
+void qvrcnn::insert_w(int stepw, int layer)
+{
+    insert_sorted(steps.stepw, layer, stepw, [](int v, int e) { return e < v; });
+}
+
+// ... and stepy in ascending order
 void qvrcnn::insert_y(int stepy, int layer)
 {
-    int i, j;
-    for (i = 0; i < layer - 1; i++)
-        if (steps.stepy[i] > stepy) {
-            for (j = layer - 1; j > i; j--) steps.stepy[j] = steps.stepy[j - 1];
-            steps.stepy[j] = stepy;
-            return;
-        }
-    steps.stepy[i] = stepy;
+    insert_sorted(steps.stepy, layer, stepy, [](int v, int e) { return e > v; });
 }
 
 qvrcnn::~qvrcnn()

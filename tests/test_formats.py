@@ -42,11 +42,28 @@ def test_quant_params_cpp_roundtrip(tmp_path, golden_dir):
     assert back == [[float(v) for v in r] for r in rows]
 
 
+# The "after net" PSNR of the 18 sequences of inference/run_all.bat:2-23, in that order, as the reference's own log
+# prints them with %f (inference/log.txt, the 18 consecutive records from lines 19164 (QP22), 18840 (QP27),
+# 19002 (QP32) and 18480 (QP37)); psnr_static_%d.data holds the same numbers as raw doubles.
+PSNR_PUBLISHED = {
+    22: (43.559227, 43.250319, 43.174014, 41.698177, 40.541803, 41.100642, 42.636192, 42.099443, 41.876322, 41.218068,
+         42.191939, 42.826159, 41.777968, 41.306464, 42.734570, 44.102494, 44.171832, 44.654846),
+    27: (40.460927, 39.007978, 41.919759, 38.916977, 37.929073, 39.458542, 37.872313, 38.800404, 38.883504, 36.778530,
+         38.594294, 39.425509, 37.441326, 37.414731, 38.612918, 41.680043, 42.163152, 42.473673),
+    32: (37.449883, 34.975122, 40.166436, 36.068996, 35.677459, 38.013338, 34.673137, 35.897398, 35.565503, 32.866749,
+         34.947060, 36.083019, 33.797820, 33.877349, 34.645364, 38.916625, 39.958420, 40.009500),
+    37: (34.466063, 32.845786, 37.733835, 33.263627, 33.344701, 36.277800, 31.794696, 33.279363, 32.156799, 29.095401,
+         31.383427, 32.835384, 30.311630, 30.598423, 31.178195, 35.822853, 37.462374, 37.195164),
+}
+
+
 @pytest.mark.parametrize("qp", [22, 27, 32, 37])
 def test_psnr_static_files(qp, golden_dir):
     d = formats.read_psnr_doubles(os.path.join(golden_dir, f"psnr_static_{qp}.data"))
     assert d.shape == (18,)
     assert np.allclose(d[:3], PSNR_HEAD[qp], atol=5e-7)
+    # all 18 doubles of the file against the published six-decimal figures
+    assert ["%.6f" % v for v in d] == ["%.6f" % v for v in PSNR_PUBLISHED[qp]]
 
 
 def test_psnr_append_and_records(tmp_path):
