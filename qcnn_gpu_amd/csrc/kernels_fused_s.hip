@@ -176,9 +176,6 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     grow += R;
 #pragma unroll
     for (int i = 0; i < R; ++i) S[i] = load_row(i);
-#ifdef QCNN_TOUCH_AHEAD
-    int touch = 0;
-#endif
     v4i Bq[2][3];  // B fragments of the current conc1 row (slot row & 1) and of the next one
 #pragma unroll
     for (int s = 0; s < 3; ++s) Bq[0][s] = *reinterpret_cast<const v4i *>(rd + s * 48);
@@ -207,17 +204,6 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
             grow += R;
 #pragma unroll
             for (int i = 0; i < R; ++i) S[i] = load_row(i);
-#ifdef QCNN_TOUCH_AHEAD
-            // one byte of every 128-byte line of the group after that: it starts its way from HBM a step early and
-            // waits in L2 (the result is never read)
-#pragma unroll
-            for (int i = 0; i < R; i += 8) {
-                const int l = lane + 64 * (i / 8);                       // line l of the group's R x 7 lines
-                const int row = grow + R + l / 7 < H + 3 ? grow + R + l / 7 : H + 3;
-                if (l < R * 7)
-                    touch += __builtin_amdgcn_raw_buffer_load_b8(conc_rsrc, row * (int)row_bytes + x0 * 48 + (l % 7) * 128, 0, 0);
-            }
-#endif
 #endif
         }
         // the fragments of the next row (the first row of the other group after the last row of this one)
@@ -352,9 +338,6 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     for (; t < t_lo; ++t) static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
     for (; t < t_hi; ++t) static_for<R>([&](auto jc) { row(jc, std::false_type{}, t); });
     for (; t < T; ++t) static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
-#ifdef QCNN_TOUCH_AHEAD
-    if (touch == 0x12345678 && a.dbg) a.dbg[0] = touch;  // keeps the touches alive
-#endif
 }
 
 hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t s)

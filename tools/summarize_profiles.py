@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Turns what tools/profile_gpu.sh left under gpurun_out/prof/ into the committed summaries under
-profiles/ (kernel statistics, counter means per dispatch, traffic.json).  Picks the newest file of
-every pass."""
+"""Turns what tools/profile_r02.sh (round 1: tools/profile_gpu.sh) left under gpurun_out/prof/ into the committed
+summaries under profiles/ (kernel statistics, counter means per dispatch, traffic.json).  Picks the newest file
+of every pass."""
 import collections
 import csv
 import glob
@@ -25,17 +25,19 @@ def newest(pattern):
 shutil.copy(newest(P + "/stats/vm/*_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(P, "bench_stats.json"), os.path.join(ROOT, "profiles", f"{tag}_bench_under_rocprof.json"))
 rows, means = [], {}
-for p in ("sq", "lds", "fetch", "write"):
+for p in ("sq", "lds", "act", "fetch", "write"):
+    if not glob.glob(f"{P}/pmc_{p}/vm/*_counter_collection.csv"):
+        continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(newest(f"{P}/pmc_{p}/vm/*_counter_collection.csv"))):
-        if "qcnn" in r["Kernel_Name"]:
-            k = "k_c1c2" if "c1c2" in r["Kernel_Name"] else "k_c3c4"
+        if "k_c1c2" in r["Kernel_Name"] or "k_c3c4" in r["Kernel_Name"]:
+            k = "k_c1c2" if "c1c2" in r["Kernel_Name"] else "k_c3c4"   # k_c3c4: kernel B, whichever form ran
             acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(acc.items()):
         rows.append((p, k, c, len(v), sum(v) / len(v)))
         means[(k, c)] = sum(v) / len(v)
 with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.csv"), "w") as f:
-    f.write("# rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1` (16 frames of 1920x1080 per dispatch); mean per dispatch\n")
+    f.write("# rocprofv3 --pmc passes of a short `python3 bench.py` run (16 frames of 1920x1080 per dispatch; see the profiling script); mean per dispatch\n")
     f.write("pass,kernel,counter,dispatches,mean_value\n")
     for r in rows:
         f.write("%s,%s,%s,%d,%.6g\n" % r)
