@@ -119,27 +119,36 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     const __amdgpu_buffer_rsrc_t conc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t *>(a.conc1 + (size_t)f * a.conc_stride), 0, (int)a.conc_stride, 0x00020000);
     // rows past the border (the last group of a band at the bottom of the frame) repeat the last border row
-    int grow = ya;  // row of the bordered image the group in flight starts at
+    int grow = ya;                                  // row of the bordered image the group in flight starts at
+    int goff = ya * (int)row_bytes + x0 * 48;       // its byte offset in the image
     const int lane_off = lane < ROW_BYTES / 16 ? lane * 16 : 0x7f000000;
-    auto load_row = [&](int i) {
+    auto load_row = [&](int i, bool clamp = true) {
 #ifdef QCNN_ABL_L2LOADS  // diagnostic builds only: every load hits a few rows that stay in L2
-        const int row = (grow + i) & 7;
+        const int off = ((grow + i) & 7) * (int)row_bytes + x0 * 48;
 #else
-        const int row = grow + i < H + 3 ? grow + i : H + 3;
+        const int off = !clamp || grow + i <= H + 3 ? goff + i * (int)row_bytes : (H + 3) * (int)row_bytes + x0 * 48;
 #endif
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(conc_rsrc, lane_off, row * (int)row_bytes + x0 * 48, 0);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(conc_rsrc, lane_off, off, 0);
         return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+    };
+    auto next_group = [&] {
+        grow += R;
+        goff += R * (int)row_bytes;
     };
     // the wave's LDS: two groups of R rows; step t reads group t & 1 while group t + 1 is written into the other
     unsigned char *wr = ring + lane * 16;
     const unsigned char *rd = ring + pix * 48 + gc * 16;  // + group * GROUP_BYTES + row * 864 + s * 48
 
-    // residual input and output: lane (pixel o, lane row 0) owns output column x0 + o, o < 14
-    // (addresses as a uniform frame base + a 32-bit lane offset: a frame holds at most 2^30 pixels)
+    // residual input and output: lane (pixel o, lane row 0) owns output column x0 + o, o < 14.  Both go through
+    // buffer descriptors of the frame (at most 2^30 bytes): a scalar row offset plus the lane's column, and for
+    // the lanes that own no output pixel an offset past the end, which a buffer store drops and a buffer load
+    // answers with zero: no address arithmetic and no exec masking per row.
     const bool outlane = g == 0 && pix < SW && x0 + pix < W;
-    const unsigned xcol = x0 + pix < W ? x0 + pix : W - 1;
-    const uint8_t *yf = a.y + (size_t)f * a.frame_stride;
-    uint8_t *recf = a.rec + (size_t)f * a.frame_stride;
+    const int out_off = outlane ? x0 + pix : 0x7f000000;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.y + (size_t)f * a.frame_stride), 0, H * W, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)f * a.frame_stride, 0, H * W, 0x00020000);
     const int addr1 = 4 * lane_of_pixel(pix + 1 < 16 ? pix + 1 : 15, 1);
     const int addr2 = 4 * lane_of_pixel(pix + 2 < 16 ? pix + 2 : 15, 2);
     // conc2 pixels outside the frame are the zero padding of C4.  Everything a lane derives from C4 belongs to one
@@ -151,6 +160,8 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // applyRes_y: ((acc + bias) * mul + half) >> shift with the bias and the rounding term in one constant (the
     // host has proved that acc, acc + bias and the whole product fit: prove_integer_path)
     const int round4 = (1 << (shift - 1)) + b4i * mul;
+    int round4v;  // in a vector register: the multiply-add takes one scalar operand only
+    asm volatile("v_mov_b32 %0, %1" : "=v"(round4v) : "s"(round4));
 
     // conc1 rows to walk: conc1 row m completes conc2 row ya - 3 + m, whose C4 product completes output row
     // ya - 4 + m, which is written while conc1 row m + 1 is processed: yb - ya + 5 rows
@@ -160,10 +171,12 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     for (int i = 0; i < R; ++i) S[i] = load_row(i);
     // residual input of output row y3 = ya - 4 + m (slot m % R): fetched one step ahead, right after the pixel of
     // output row y3 - R has been used
-    auto yoff = [&](int y3) { return (unsigned)(y3 < 0 ? 0 : y3 >= H ? H - 1 : y3) * (unsigned)W + xcol; };
+    auto load_y = [&](int y3) {  // rows outside the frame are never used: clamped
+        return __builtin_amdgcn_raw_buffer_load_b8(y_rsrc, out_off, (y3 < 0 ? 0 : y3 >= H ? H - 1 : y3) * W, 0);
+    };
     unsigned char ypix[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) ypix[j] = yf[yoff(ya - 4 + j)];
+    for (int j = 0; j < R; ++j) ypix[j] = load_y(ya - 4 + j);
 
     v4i acc[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
     v4i a32[2][2] = {{v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}, {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}};
@@ -173,13 +186,15 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // group 0 into LDS, group 1 on its way, the fragments of row 0 requested
 #pragma unroll
     for (int i = 0; i < R; ++i) *reinterpret_cast<v4i *>(wr + i * ROW_BYTES) = S[i];  // ascending: see above
-    grow += R;
+    next_group();
 #pragma unroll
     for (int i = 0; i < R; ++i) S[i] = load_row(i);
     v4i Bq[2][3];  // B fragments of the current conc1 row (slot row & 1) and of the next one
 #pragma unroll
     for (int s = 0; s < 3; ++s) Bq[0][s] = *reinterpret_cast<const v4i *>(rd + s * 48);
 
+    int y3w = (ya - 5) * W;  // (output row of the current conc1 row) * W: the row offset of its store
+    const int RW = R * W;
     STAMP_INIT();
     // One conc1 row.  CHECK = false: a step whose six conc2 rows lie inside the frame and whose six output rows lie
     // inside the band, in a strip with no column outside the frame; every test below is then known to hold.
@@ -201,9 +216,9 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
             // unconditional (the last two steps fetch rows nobody reads: load_row clamps them into the image): the
             // compiler counts only loads that are certain to be issued when it sizes the vmcnt waits of the byte
             // loads around them, and a wait sized without these would wait for THEM
-            grow += R;
+            next_group();
 #pragma unroll
-            for (int i = 0; i < R; ++i) S[i] = load_row(i);
+            for (int i = 0; i < R; ++i) S[i] = load_row(i, CHECK);
 #endif
         }
         // the fragments of the next row (the first row of the other group after the last row of this one)
@@ -286,20 +301,19 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
                 out = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
             } else {
                 // the same in integers (the host has proved the operand ranges, see prove_integer_path)
-                const int temp = (__mul24(sum, mul) + round4) >> shift;
+                const int temp = (__mul24(sum, mul) + round4v) >> shift;
                 const int rec = (int)ypix[jp] + temp;
                 out = (uint8_t)min(max(rec, 0), 255);
             }
-#ifdef QCNN_ABL_NOSTORE
-            if (outlane && out == 77 && y3 == 1) recf[(unsigned)y3 * (unsigned)W + (unsigned)(x0 + pix)] = out;
-#else
-            if (outlane) recf[(unsigned)y3 * (unsigned)W + (unsigned)(x0 + pix)] = out;
+#ifndef QCNN_ABL_NOSTORE
+            __builtin_amdgcn_raw_buffer_store_b8(out, rec_rsrc, out_off, y3w, 0);
 #endif
         }
 #ifndef QCNN_ABL_NOYLOAD
         // the residual input this slot needs one step from now (a row past the frame is never used: clamped)
-        ypix[jp] = yf[CHECK ? yoff(y3 + R) : (unsigned)(y3 + R < H ? y3 + R : H - 1) * (unsigned)W + xcol];
+        ypix[jp] = CHECK ? load_y(y3 + R) : __builtin_amdgcn_raw_buffer_load_b8(y_rsrc, out_off, y3w + RW, 0);
 #endif
+        y3w += W;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!EXACT) {
             REQ_PIECE(3, true);
@@ -326,9 +340,13 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // rows ya - 5 + R t .. + R - 1 inside the band, and the strip has no column outside the frame.  Three loops
     // rather than a test per step: two copies of the unrolled step inside one loop cost the register allocator
     // dozens of spills.
+    // ... and the residual rows they prefetch (output row + R) and the conc1 group they request (group t + 2) lie
+    // inside the frame / the bordered image, so that the fast loop clamps nothing.
     int t_lo = T, t_hi = T;
     if (!edge_strip) {
-        const int last = (H - 3 - ya < yb - 1 - ya ? H - 3 - ya : yb - 1 - ya);  // R t may be at most this
+        int last = (H - 3 - ya < yb - 1 - ya ? H - 3 - ya : yb - 1 - ya);  // R t may be at most this
+        last = last < H - 2 * R + 5 - ya ? last : H - 2 * R + 5 - ya;      // ya - 5 + R t + 2 R - 1 <= H - 1
+        last = last < H + 4 - 3 * R - ya ? last : H + 4 - 3 * R - ya;      // ya + (t + 3) R - 1 <= H + 3
         t_lo = ya >= 3 ? 1 : (3 - ya + R - 1) / R > 1 ? (3 - ya + R - 1) / R : 1;
         t_hi = last >= 0 ? last / R + 1 : 0;
         if (t_hi > T) t_hi = T;
