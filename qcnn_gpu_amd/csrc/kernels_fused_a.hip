@@ -150,15 +150,49 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
     }
 }
 
+// One row of c2_store on the integer path: requant of row y of `acc` and its 12 bytes per lane.
+template <int ROWS>
+struct C2RowOut {
+    int8_t *out;       // the lane's 12 bytes of row 0
+    size_t row_bytes;
+    int rows_ok;       // rows of the block inside the frame
+    bool col_ok;       // the lane's column is inside the frame
+    __device__ __forceinline__ C2RowOut(int R0, int cb, int c, int g, int8_t *concf, int x0, int y0, int H, int W)
+    {
+        const int gx = x0 + cb + c, gy0 = y0 + R0;
+        row_bytes = (size_t)conc_wp(W) * 48;
+        out = concf + (size_t)(gy0 + 2) * row_bytes + (size_t)(gx + 2) * 48 + 12 * g;
+        rows_ok = H - gy0;
+        col_ok = gx < W;
+    }
+    __device__ __forceinline__ void store(const C2Acc<ROWS> &acc, int y, const C2Consts &k) const
+    {
+        unsigned d0, d1, d2;
+        requant12_int(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, d0, d1, d2);
+        if (y < rows_ok && col_ok) {
+            unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+            dst[0] = d0;
+            dst[1] = d1;
+            dst[2] = d2;
+        }
+    }
+};
+
 // C2_1 (3x3, 64 -> 32) and C2_2 (5x5, 64 -> 16) for ROWS output rows x 16 columns of the tile in `buf`
 // (rows R0 .. R0+ROWS-1, columns cb .. cb+15) as 16x16x64 MFMAs into `acc`.  LDS row = output row + r,
 // LDS column = output column + s (the 3x3 taps are r-1, s-1 of the 5x5 window).  The LDS reads of
 // the first steps are issued, then `between()` runs (it may still read the previous contents of
 // `acc`), then the accumulators are set to the biases and the MFMA steps run.
-template <bool EXACT, int ROWS, typename F>
+//
+// OVERLAP > 0 (integer path of the consumers): `acc` still holds the previous tile.  Column s = 0 of
+// the kernel walks the input rows top to bottom and step yy touches output rows <= yy only, so row yy
+// of the previous tile is handed to row_done(yy) (requant + store) right before step yy and its
+// accumulators restart from the biases; `between()` runs before step OVERLAP instead of before step 0.
+template <bool EXACT, int ROWS, int OVERLAP = 0, typename F, typename G = void (*)(int)>
 __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *buf, int R0, int cb, int c, int g, const v4i *w22,
-                                        const v4i *w21, const C2Consts &k, F &&between)
+                                        const v4i *w21, const C2Consts &k, F &&between, G &&row_done = nullptr)
 {
+    static_assert(OVERLAP == 0 || (OVERLAP >= ROWS && OVERLAP < C2Plan<ROWS>::STEPS), "every row is handed over before the release");
     using namespace ka;
     using PO = C2PlanOf<ROWS>;  // PO::P is the plan
     constexpr int IN = C2Plan<ROWS>::IN, STEPS = C2Plan<ROWS>::STEPS;
@@ -178,18 +212,34 @@ __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *b
     };
     static_range<0, c2_issued<ROWS>(-1)>(issue);
     __builtin_amdgcn_sched_barrier(0);
-    between();
-    __builtin_amdgcn_sched_barrier(0);
-    C2_STAMP();
+    if constexpr (OVERLAP == 0) {
+        between();
+        __builtin_amdgcn_sched_barrier(0);
+        C2_STAMP();
 #pragma unroll
-    for (int y = 0; y < ROWS; ++y) {
-        acc.a21[0][y] = k.b0;
-        acc.a21[1][y] = k.b1;
-        acc.a22[y] = k.b2;
+        for (int y = 0; y < ROWS; ++y) {
+            acc.a21[0][y] = k.b0;
+            acc.a21[1][y] = k.b1;
+            acc.a22[y] = k.b2;
+        }
     }
     static_for<STEPS>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
         constexpr int s = I / IN, yy = I % IN;
+        if constexpr (OVERLAP > 0) {
+            if constexpr (I < ROWS) {
+                row_done(I);
+                acc.a21[0][I] = k.b0;
+                acc.a21[1][I] = k.b1;
+                acc.a22[I] = k.b2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (I == OVERLAP) {
+                between();
+                __builtin_amdgcn_sched_barrier(0);
+                C2_STAMP();
+            }
+        }
         static_range<c2_issued<ROWS>(I - 1), c2_issued<ROWS>(I)>(issue);
         const v4i B = item[PO::P.iB[s][yy]];
         static_for<5>([&](auto rc) {
@@ -216,6 +266,15 @@ __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *b
 #define C2_CONS_ROWS_N 8
 #endif
 constexpr int C2_CONS_ROWS = C2_CONS_ROWS_N;
+// MFMA steps of a tile that a consumer runs while it still requantises and stores the previous one
+// (with the producers parked at the barrier inside the step); 0 = store first, then all the MFMAs.
+// Measured on 1080p frames, us per frame of this kernel: 0: 75.6, 12: 77.2, 18: 79.6, 24: 80.6, 30:
+// 83.2 -- the producers' later start costs more than the consumers' MFMAs moved out of the shared phase
+// save, so the default stays 0.
+#ifndef C2_OVERLAP_N
+#define C2_OVERLAP_N 0
+#endif
+constexpr int C2_OVERLAP = C2_OVERLAP_N;
 
 // End of a pipeline step: every LDS write of this wave has landed, then the workgroup barrier.
 // (A raw s_barrier: global loads and stores in flight are deliberately not waited for.)
@@ -554,7 +613,15 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                     c2_store<EXACT, C2_CONS_ROWS>(acc, R0, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
                                                   pos.ty * TH, H, W);
                 } else {
-                    c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_then_release);
+                    if constexpr (C2_OVERLAP > 0) {
+                        const C2RowOut<C2_CONS_ROWS> ro(R0, cb, c, g, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
+                                                        held.ty * TH, have ? H : 0, W);
+                        c2_mfma<EXACT, C2_CONS_ROWS, C2_OVERLAP>(
+                            acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, [] { mid_barrier(); },
+                            [&](int y) { ro.store(acc, y, kc); });
+                    } else {
+                        c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_then_release);
+                    }
                     held = pos;
                     have = true;
                 }

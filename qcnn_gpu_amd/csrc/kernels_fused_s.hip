@@ -3,9 +3,10 @@
 //
 // No workgroup barrier, no shared tile: every WAVE is on its own.  A wave owns a strip of 14 output
 // columns and walks it down a band of rows, one conc1 row at a time:
-//   * conc1 row y1 of the strip (18 pixels = 864 contiguous bytes of the bordered HBM image) arrives in
-//     LDS in groups of ks::R rows, staged through registers one group ahead of its use; LDS is only the
-//     place where the row turns into MFMA B fragments (16 region pixels x 3 column shifts), each read once;
+//   * conc1 row y1 of the strip (18 pixels = 864 contiguous bytes of the bordered HBM image) is loaded
+//     straight into LDS (buffer load with the LDS bit: no register in between) into a ring of 2 ks::R rows,
+//     twelve rows ahead of its use; LDS is only the place where the row turns into MFMA B fragments (16
+//     region pixels x 3 column shifts), each read once.  The residual input Y travels the same way;
 //   * C3_1 (3x3) as nine 16x16x64 MFMAs per row into three rolling accumulators (conc1 row y1 feeds the
 //     conc2 rows y1+1, y1, y1-1 with kernel rows 0, 1, 2), C3_2 (1x1) as two more on the centre fragment;
 //   * when conc1 row y1 is done, conc2 row y1-1 is complete: its requantised bytes never leave the lane's
@@ -44,15 +45,32 @@ __device__ __forceinline__ int lane_of_pixel(int pix, int g)
 #define MFMA3(a, b, c) mfma16(a, b, c)
 #endif
 
+// Cache policy bits of the conc1 loads.  conc1 is read once (apart from the four columns two neighbouring strips
+// share): the non-temporal hint takes 8 % off the kernel, the scope bits sc0 / sc1 change nothing (measured;
+// experiment builds pick another policy with -DQCNN_CONC_LOAD_POLICY=n).  The same hint on the Y loads and the
+// byte stores of the output costs 16 %: their lines are shared by neighbouring strips and rows.
+#ifndef QCNN_CONC_LOAD_POLICY
+#define QCNN_CONC_LOAD_POLICY 1
+#endif
+#if QCNN_CONC_LOAD_POLICY == 0
+#define QCNN_CONC_LOAD_AUX ""
+#elif QCNN_CONC_LOAD_POLICY == 1
+#define QCNN_CONC_LOAD_AUX " nt"
+#elif QCNN_CONC_LOAD_POLICY == 2
+#define QCNN_CONC_LOAD_AUX " sc1"
+#elif QCNN_CONC_LOAD_POLICY == 3
+#define QCNN_CONC_LOAD_AUX " sc0"
+#elif QCNN_CONC_LOAD_POLICY == 4
+#define QCNN_CONC_LOAD_AUX " sc0 sc1"
+#else
+#define QCNN_CONC_LOAD_AUX " sc0 sc1 nt"
+#endif
+
 template <bool EXACT>
 __global__ __launch_bounds__(ks::WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_units)
 {
-#ifdef QCNN_ABL_LDS_PAD  // diagnostic builds only: fewer resident workgroups per CU
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * RING_BYTES + QCNN_ABL_LDS_PAD];
-#else
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * RING_BYTES];
-#endif
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * WAVE_LDS];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroups are dealt to the 8 XCDs round robin; XCD x takes the x-th eighth of the units, so that strips that
@@ -69,7 +87,8 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     const int x0 = strip * SW, ya = seg * seg_rows;
     const int yb = ya + seg_rows < H ? ya + seg_rows : H;  // output rows ya .. yb-1
     if (ya >= yb) return;
-    unsigned char *ring = smem + wv * RING_BYTES;
+    unsigned char *ring = smem + wv * WAVE_LDS;   // conc1 rows: two groups of R
+    unsigned char *yring = ring + RING_BYTES;     // Y rows: 2 R x 16 dwords
     const int g = lane >> 4;
     const int pix = kb_pixel_of_lane(lane & 15);  // region pixel of this lane: image column x0 - 1 + pix
     const int gc = kb_chunk_of_kgroup(g);
@@ -108,47 +127,70 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     const int b4i = EXACT ? 0 : a.bias_i[BIAS_OFF[5]];
     const int mul = a.rq[5].mul, shift = a.rq[5].shift;
 
-    // staging: one wave-wide 16-byte load per conc1 row.  Lane l < 54 fetches piece l of the row's 864 bytes; the
-    // other ten lanes carry an offset past the end of the buffer, for which a buffer load fetches nothing and
-    // returns zeros; they drop them into LDS behind the row, where the next row's pieces overwrite them (a wave's
-    // LDS writes land in order) or, after the last row of a group, the slack behind the group takes them.
-    // conc1 row m of this band (m = 0, 1, ...) is image row ya - 2 + m = row ya + m of the bordered image; the
-    // strip's first column x0 - 2 is column x0 of it.  The loads are buffer loads: a uniform descriptor of this
-    // frame's image, a scalar offset per row, and lane * 16, so that no lane carries an address.
-    const size_t row_bytes = (size_t)conc_wp(W) * 48;
+    // staging: conc1 row m of this band (m = 0, 1, ...) is image row ya - 2 + m = row ya + m of the bordered
+    // image; the strip's first column x0 - 2 is column x0 of it: 864 contiguous bytes.  One buffer load with the
+    // LDS bit moves a row: lane l < 54 fetches piece l and the hardware writes it to LDS at M0 + 16 l, no register
+    // in between (the other ten lanes are switched off for it).  The row goes into slot m % 2R of the wave's
+    // ring and is requested while conc1 row m - 2R is processed, whose fragments left that slot a row earlier:
+    // twelve rows of flight time.  The residual input Y of an output row travels the same way (a byte load with
+    // the LDS bit: lane o < 16 drops pixel x0 + o as a dword at M0 + 4 o) into a ring of its own.
+    //
+    // The compiler knows nothing of these loads, so EVERY vector memory instruction of the main loop is inline
+    // assembly and the waits are counted by hand.  Each conc1 row issues exactly three of them, in this order:
+    // the output byte store, the conc1 load, the Y load (a store or load that is not wanted carries an offset
+    // past the end of its buffer, which the hardware drops, resp. answers with zeros).  The vector memory
+    // instructions of a wave complete in the order issued, and row m needs the conc1 load that row m - 11
+    // issued (the fragments of row m + 1) and the Y load that row m - 12 issued: behind the younger of the two
+    // 1 + 3 * 10 = 31 instructions may still be in flight.
+    const int row_bytes = conc_wp(W) * 48;
     const __amdgpu_buffer_rsrc_t conc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t *>(a.conc1 + (size_t)f * a.conc_stride), 0, (int)a.conc_stride, 0x00020000);
-    // rows past the border (the last group of a band at the bottom of the frame) repeat the last border row
-    int grow = ya;                                  // row of the bordered image the group in flight starts at
-    int goff = ya * (int)row_bytes + x0 * 48;       // its byte offset in the image
-    const int lane_off = lane < ROW_BYTES / 16 ? lane * 16 : 0x7f000000;
-    auto load_row = [&](int i, bool clamp = true) {
-#ifdef QCNN_ABL_L2LOADS  // diagnostic builds only: every load hits a few rows that stay in L2
-        const int off = ((grow + i) & 7) * (int)row_bytes + x0 * 48;
-#else
-        const int off = !clamp || grow + i <= H + 3 ? goff + i * (int)row_bytes : (H + 3) * (int)row_bytes + x0 * 48;
-#endif
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(conc_rsrc, lane_off, off, 0);
-        return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
-    };
-    auto next_group = [&] {
-        grow += R;
-        goff += R * (int)row_bytes;
-    };
-    // the wave's LDS: two groups of R rows; step t reads group t & 1 while group t + 1 is written into the other
-    unsigned char *wr = ring + lane * 16;
-    const unsigned char *rd = ring + pix * 48 + gc * 16;  // + group * GROUP_BYTES + row * 864 + s * 48
-
-    // residual input and output: lane (pixel o, lane row 0) owns output column x0 + o, o < 14.  Both go through
-    // buffer descriptors of the frame (at most 2^30 bytes): a scalar row offset plus the lane's column, and for
-    // the lanes that own no output pixel an offset past the end, which a buffer store drops and a buffer load
-    // answers with zero: no address arithmetic and no exec masking per row.
-    const bool outlane = g == 0 && pix < SW && x0 + pix < W;
-    const int out_off = outlane ? x0 + pix : 0x7f000000;
+    // residual input and output go through buffer descriptors of the frame (at most 2^30 bytes): a scalar row
+    // offset plus the lane's column, or an offset past the end for the lanes that own no pixel
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(a.y + (size_t)f * a.frame_stride), 0, H * W, 0x00020000);
     const __amdgpu_buffer_rsrc_t rec_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(a.rec + (size_t)f * a.frame_stride, 0, H * W, 0x00020000);
+    constexpr int OOB = 0x7f000000;
+    const int lane16 = lane * 16;
+    const int y_voff = (lane < SW && x0 + lane < W) ? lane : OOB;
+    const unsigned long long row_lanes = (1ull << (ROW_BYTES / 16)) - 1;
+    const unsigned ring_s = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);  // LDS byte addresses
+    const unsigned yring_s = ring_s + RING_BYTES;
+    // requests conc1 row `crow` of the bordered image and the Y pixels of output row `yrow` into ring slot
+    // (grp, j): row j of group grp
+    auto request = [&](int grp, int j, int crow, int yrow, bool clamp) {
+        if (clamp) {  // rows past the border / outside the frame are never used: any row inside will do
+            crow = crow <= H + 3 ? crow : H + 3;
+            yrow = yrow < 0 ? 0 : yrow >= H ? H - 1 : yrow;
+        }
+#ifdef QCNN_ABL_L2LOADS  // diagnostic builds only: every load hits a few rows that stay in L2
+        crow &= 7;
+#endif
+        const unsigned lds_c = ring_s + grp * GROUP_BYTES + j * ROW_BYTES, lds_y = yring_s + (grp * R + j) * 64;
+        const int off_c = crow * row_bytes + x0 * 48, off_y = yrow * W + x0;
+        unsigned long long saved;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_mov_b64 exec, %2\n\t"
+                     "buffer_load_dwordx4 %3, %4, %5 offen" QCNN_CONC_LOAD_AUX " lds\n\t"
+                     "s_mov_b32 m0, %6\n\t"
+                     "s_mov_b64 exec, 0xffff\n\t"
+                     "buffer_load_ubyte %7, %8, %9 offen lds\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(saved)
+                     : "s"(lds_c), "s"(row_lanes), "v"(lane16), "s"(conc_rsrc), "s"(off_c), "s"(lds_y), "v"(y_voff), "s"(y_rsrc),
+                       "s"(off_y)
+                     : "memory");
+    };
+    // the lane's read addresses: B fragments of a conc1 row (+ group * GROUP_BYTES + row * 864 + s * 48), the Y
+    // pixel of its column (+ slot * 64)
+    const unsigned char *rd = ring + pix * 48 + gc * 16;
+    const unsigned char *rdy = yring + pix * 4;
+
+    // output: lane (pixel o, lane row 0) owns output column x0 + o, o < 14
+    const bool outlane = g == 0 && pix < SW && x0 + pix < W;
+    const int out_off = outlane ? x0 + pix : OOB;
     const int addr1 = 4 * lane_of_pixel(pix + 1 < 16 ? pix + 1 : 15, 1);
     const int addr2 = 4 * lane_of_pixel(pix + 2 < 16 ? pix + 2 : 15, 2);
     // conc2 pixels outside the frame are the zero padding of C4.  Everything a lane derives from C4 belongs to one
@@ -164,37 +206,26 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     asm volatile("v_mov_b32 %0, %1" : "=v"(round4v) : "s"(round4));
 
     // conc1 rows to walk: conc1 row m completes conc2 row ya - 3 + m, whose C4 product completes output row
-    // ya - 4 + m, which is written while conc1 row m + 1 is processed: yb - ya + 5 rows
+    // ya - 4 + m, which is written while conc1 row m + 1 is processed (so row m writes output row ya - 5 + m):
+    // yb - ya + 5 rows
     const int T = (yb - ya + 5 + R - 1) / R;
-    v4i S[R];
+    // the ring's first 2R rows, all landed before the first row starts
 #pragma unroll
-    for (int i = 0; i < R; ++i) S[i] = load_row(i);
-    // residual input of output row y3 = ya - 4 + m (slot m % R): fetched one step ahead, right after the pixel of
-    // output row y3 - R has been used
-    auto load_y = [&](int y3) {  // rows outside the frame are never used: clamped
-        return __builtin_amdgcn_raw_buffer_load_b8(y_rsrc, out_off, (y3 < 0 ? 0 : y3 >= H ? H - 1 : y3) * W, 0);
-    };
-    unsigned char ypix[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) ypix[j] = load_y(ya - 4 + j);
+    for (int i = 0; i < 2 * R; ++i) request(i / R, i % R, ya + i, ya - 5 + i, true);
+    // (as a builtin: the compiler then knows that its own loads above, the weights and biases, have landed too,
+    // and places no wait for them inside the loops)
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    asm volatile("" ::: "memory");
 
     v4i acc[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
     v4i a32[2][2] = {{v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}, {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}};
     int Pa = 0, Pb = 0;            // partial sums (kernel rows) of the two output rows still open
     v4i D4p = {0, 0, 0, 0};        // C4 product of the conc2 row completed by the previous conc1 row
 
-    // group 0 into LDS, group 1 on its way, the fragments of row 0 requested
-#pragma unroll
-    for (int i = 0; i < R; ++i) *reinterpret_cast<v4i *>(wr + i * ROW_BYTES) = S[i];  // ascending: see above
-    next_group();
-#pragma unroll
-    for (int i = 0; i < R; ++i) S[i] = load_row(i);
     v4i Bq[2][3];  // B fragments of the current conc1 row (slot row & 1) and of the next one
 #pragma unroll
     for (int s = 0; s < 3; ++s) Bq[0][s] = *reinterpret_cast<const v4i *>(rd + s * 48);
 
-    int y3w = (ya - 5) * W;  // (output row of the current conc1 row) * W: the row offset of its store
-    const int RW = R * W;
     STAMP_INIT();
     // One conc1 row.  CHECK = false: a step whose six conc2 rows lie inside the frame and whose six output rows lie
     // inside the band, in a strip with no column outside the frame; every test below is then known to hold.
@@ -206,21 +237,11 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         static_assert(R % 2 == 0 && R % 3 == 0, "the fragment and accumulator slots repeat with the step");
         v4i(&B)[3] = Bq[j & 1];
         v4i(&Bn)[3] = Bq[(j + 1) & 1];
-        if constexpr (j == R - 2) {
-            // group t + 1 has had four rows' time to arrive: into the other half of the LDS buffer, and group t + 2
-            // sets out
-            unsigned char *wro = wr + ((t + 1) & 1) * GROUP_BYTES;
-#pragma unroll
-            for (int i = 0; i < R; ++i) *reinterpret_cast<v4i *>(wro + i * ROW_BYTES) = S[i];
-#ifndef QCNN_ABL_NOLOAD
-            // unconditional (the last two steps fetch rows nobody reads: load_row clamps them into the image): the
-            // compiler counts only loads that are certain to be issued when it sizes the vmcnt waits of the byte
-            // loads around them, and a wait sized without these would wait for THEM
-            next_group();
-#pragma unroll
-            for (int i = 0; i < R; ++i) S[i] = load_row(i, CHECK);
-#endif
-        }
+        // conc1 row m + 1 and the Y pixels of this row's output row have landed (see the count above; the last two
+        // steps request nothing, so only their 10 stores are certain to be younger)
+        if (CHECK && t >= T - 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+        const int yv = *reinterpret_cast<const int *>(rdy + ((t & 1) * R + j) * 64);
         // the fragments of the next row (the first row of the other group after the last row of this one)
         if constexpr (j + 1 < R) {
 #pragma unroll
@@ -288,32 +309,29 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         if constexpr (!EXACT) REQ_PIECE(2, false);
         __builtin_amdgcn_sched_barrier(0);
         STAMP();
-        // ---- applyRes_y of output row y3 = y2 - 2
+        // ---- applyRes_y of output row y3 = y2 - 2 (stored only if it lies in the band), then the requests for the
+        // slots this row has emptied
         const int y3 = y2 - 2;
-        if (!CHECK || (y3 >= ya && y3 < yb)) {
+        {
             const int sum = P + v1 + v2;  // C4 accumulator (its bias sits in round4)
-            uint8_t out;
+            int out;
             if constexpr (EXACT) {
                 const float u = (float)sum + b4;  // C4.u, inference/cnn.cu:148-155 (b4i is 0 on this path)
                 int temp = (int)u;                // applyRes_GPU_y, inference/cnn.cu:515-520
                 temp = (int)((unsigned)temp * (unsigned)mul + (1u << (shift - 1))) >> shift;
-                const short rec = (short)((int)ypix[jp] + temp);
-                out = rec > 255 ? (uint8_t)255 : rec < 0 ? (uint8_t)0 : (uint8_t)rec;
+                const short rec = (short)(yv + temp);
+                out = rec > 255 ? 255 : rec < 0 ? 0 : rec;
             } else {
                 // the same in integers (the host has proved the operand ranges, see prove_integer_path)
                 const int temp = (__mul24(sum, mul) + round4v) >> shift;
-                const int rec = (int)ypix[jp] + temp;
-                out = (uint8_t)min(max(rec, 0), 255);
+                out = min(max(yv + temp, 0), 255);
             }
-#ifndef QCNN_ABL_NOSTORE
-            __builtin_amdgcn_raw_buffer_store_b8(out, rec_rsrc, out_off, y3w, 0);
-#endif
+            const int voff = (!CHECK || (y3 >= ya && y3 < yb)) ? out_off : OOB;
+            asm volatile("buffer_store_byte %0, %1, %2, %3 offen" ::"v"(out), "v"(voff), "s"(rec_rsrc), "s"(y3 * W) : "memory");
         }
-#ifndef QCNN_ABL_NOYLOAD
-        // the residual input this slot needs one step from now (a row past the frame is never used: clamped)
-        ypix[jp] = CHECK ? load_y(y3 + R) : __builtin_amdgcn_raw_buffer_load_b8(y_rsrc, out_off, y3w + RW, 0);
-#endif
-        y3w += W;
+        // (rows past the last one the band walks are not requested: when the wave ends and its LDS is handed to
+        // the next workgroup, no load may still be on its way into it)
+        if (!CHECK || t <= T - 3) request(t & 1, j, ya + m0 + j + 2 * R, y3 + 2 * R, CHECK);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!EXACT) {
             REQ_PIECE(3, true);
@@ -340,16 +358,16 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // rows ya - 5 + R t .. + R - 1 inside the band, and the strip has no column outside the frame.  Three loops
     // rather than a test per step: two copies of the unrolled step inside one loop cost the register allocator
     // dozens of spills.
-    // ... and the residual rows they prefetch (output row + R) and the conc1 group they request (group t + 2) lie
-    // inside the frame / the bordered image, so that the fast loop clamps nothing.
+    // ... and the residual rows (output row + 2 R) and the conc1 rows (row + 2 R) they request lie inside the
+    // frame / the bordered image, so that the fast loop clamps nothing.
     int t_lo = T, t_hi = T;
     if (!edge_strip) {
         int last = (H - 3 - ya < yb - 1 - ya ? H - 3 - ya : yb - 1 - ya);  // R t may be at most this
-        last = last < H - 2 * R + 5 - ya ? last : H - 2 * R + 5 - ya;      // ya - 5 + R t + 2 R - 1 <= H - 1
+        last = last < H + 5 - 3 * R - ya ? last : H + 5 - 3 * R - ya;      // ya - 5 + R t + 3 R - 1 <= H - 1
         last = last < H + 4 - 3 * R - ya ? last : H + 4 - 3 * R - ya;      // ya + (t + 3) R - 1 <= H + 3
         t_lo = ya >= 3 ? 1 : (3 - ya + R - 1) / R > 1 ? (3 - ya + R - 1) / R : 1;
         t_hi = last >= 0 ? last / R + 1 : 0;
-        if (t_hi > T) t_hi = T;
+        if (t_hi > T - 2) t_hi = T - 2 > 0 ? T - 2 : 0;  // the last two steps request nothing
         if (t_lo > t_hi) t_lo = t_hi;
     }
     int t = 0;

@@ -59,11 +59,14 @@ static_assert(LDS_BYTES <= 160 * 1024, "kernel B exceeds the 160 KiB of LDS of o
 namespace ks {
 constexpr int SW = 14;                        // output columns of a strip (C3 region 16, conc1 18 columns)
 constexpr int CW = SW + 4;                    // conc1 columns a strip reads (halo 2)
-constexpr int R = 6;                          // conc1 rows staged per step
+constexpr int R = 6;                          // conc1 rows per step of the unrolled row loop
 constexpr int ROW_BYTES = CW * 48;            // one conc1 row of a strip: 864 contiguous bytes of the HBM image
-constexpr int GROUP_BYTES = R * ROW_BYTES + 192;  // a staged group of R rows (+ slack, see kernels_fused_s.hip)
-constexpr int RING_BYTES = 2 * GROUP_BYTES;       // LDS of one wave: two groups
+constexpr int GROUP_BYTES = R * ROW_BYTES + 64;   // R rows (+ slack: a fragment read runs 16 bytes past its pixel)
+constexpr int RING_BYTES = 2 * GROUP_BYTES;       // conc1 ring of one wave: 2 R row slots
+constexpr int YRING_BYTES = 2 * R * 64;           // Y ring of one wave: 2 R slots of 16 dwords (one pixel each)
+constexpr int WAVE_LDS = RING_BYTES + YRING_BYTES;
 constexpr int WAVES = 4;                      // waves per workgroup (they never synchronise)
+static_assert(3 * WAVES * WAVE_LDS <= 160 * 1024, "three workgroups per CU");
 }  // namespace ks
 
 // The conc1 hand-off image in HBM: int8 [H + 4][W + 4][48] per frame, the frame at rows 2..H+1, columns

@@ -1,0 +1,105 @@
+// Diagnostic microbenchmark (never shipped): how MFMA and vector ALU instructions of the waves that
+// share a SIMD overlap on gfx950.  One 512- or 768-thread workgroup per CU; wave w runs on SIMD w & 3.
+// Each wave runs `iters` times a body of M independent 16x16x64 int8 MFMAs and V independent
+// v_mad_i32_i24, chosen per wave "slot" (w >> 2), and reports its cycles.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int M, int V>
+__device__ __forceinline__ void body(v4i (&acc)[8], int (&x)[8], v4i A, v4i B, int mul, int add)
+{
+#pragma unroll
+    for (int i = 0; i < (M > V ? M : V); ++i) {
+        if (i < M) acc[i & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[i & 7], 0, 0, 0);
+        // V / M vector instructions after each MFMA (all of them when M == 0)
+        constexpr int per = M ? (V + M - 1) / M : 1;
+        if (M == 0 || i < M) {
+#pragma unroll
+            for (int j = 0; j < per; ++j) {
+                const int idx = M ? i * per + j : i;
+                if (idx < V) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(x[idx & 7]) : "v"(mul), "v"(add));
+            }
+        }
+    }
+}
+
+template <int M, int V>
+__device__ __forceinline__ long long run(int iters, v4i A, v4i B, int seed, int *sink)
+{
+    v4i acc[8];
+    int x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = v4i{seed, i, 0, 0}, x[i] = seed + i;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        body<M, V>(acc, x, A, B, seed | 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const long long t1 = clock64();
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3] + x[i];
+    if (s == 0x12345678) *sink = s;
+    return t1 - t0;
+}
+
+// role: 0 idle, 1 MFMA x16, 2 VALU x32, 3 MFMA 8 + VALU 8, 4 MFMA 8 + VALU 16, 5 MFMA 8 + VALU 24, 6 MFMA 8 + VALU 32, 7 VALU x16+MFMA x2
+__global__ void k(int r0, int r1, int r2, int iters, long long *out, int *sink)
+{
+    const int w = threadIdx.x >> 6, slot = w >> 2;
+    const int role = slot == 0 ? r0 : slot == 1 ? r1 : r2;
+    const v4i A = {(int)threadIdx.x, 1, 2, 3}, B = {4, 5, (int)threadIdx.x, 7};
+    __syncthreads();
+    long long c = 0;
+    switch (role) {
+    case 1: c = run<16, 0>(iters, A, B, threadIdx.x, sink); break;
+    case 2: c = run<0, 32>(iters, A, B, threadIdx.x, sink); break;
+    case 3: c = run<8, 8>(iters, A, B, threadIdx.x, sink); break;
+    case 4: c = run<8, 16>(iters, A, B, threadIdx.x, sink); break;
+    case 5: c = run<8, 24>(iters, A, B, threadIdx.x, sink); break;
+    case 6: c = run<8, 32>(iters, A, B, threadIdx.x, sink); break;
+    case 7: c = run<2, 16>(iters, A, B, threadIdx.x, sink); break;
+    case 8: __builtin_amdgcn_s_setprio(3); c = run<16, 0>(iters, A, B, threadIdx.x, sink); break;
+    case 9: c = run<0, 64>(iters, A, B, threadIdx.x, sink); break;
+    default: break;
+    }
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[w] = c;
+}
+
+int main(int argc, char **argv)
+{
+    long long *d;
+    int *sink;
+    hipMalloc(&d, 12 * 8);
+    hipMalloc(&sink, 4);
+    const int iters = 2000;
+    const int cases[][4] = {
+        // waves per SIMD, role of slot 0, 1, 2
+        {1, 1, 0, 0}, {1, 2, 0, 0}, {1, 3, 0, 0}, {1, 4, 0, 0}, {1, 5, 0, 0}, {1, 6, 0, 0}, {1, 7, 0, 0},
+        {2, 1, 2, 0}, {2, 1, 1, 0}, {2, 2, 2, 0}, {2, 3, 3, 0}, {2, 4, 4, 0}, {2, 5, 5, 0}, {2, 1, 7, 0},
+        {2, 2, 1, 0}, {2, 9, 1, 0}, {2, 9, 8, 0}, {2, 7, 1, 0}, {2, 7, 8, 0}, {2, 1, 9, 0},
+        {3, 1, 2, 2}, {3, 1, 1, 2}, {3, 3, 3, 3}, {3, 4, 4, 4}, {3, 5, 5, 5}, {3, 1, 1, 1}, {3, 2, 2, 2}, {3, 1, 7, 7},
+    };
+    const char *names[] = {"idle", "M16", "V32", "M8V8", "M8V16", "M8V24", "M8V32", "M2V16", "M16hi", "V64"};
+    const int nm[] = {0, 16, 0, 8, 8, 8, 8, 2, 16, 0}, nv[] = {0, 0, 32, 8, 16, 24, 32, 16, 0, 64};
+    for (auto &cs : cases) {
+        const int waves = cs[0];
+        for (int rep = 0; rep < 2; ++rep) {
+            hipMemset(d, 0, 12 * 8);
+            hipLaunchKernelGGL(k, dim3(256), dim3(256 * waves), 0, 0, cs[1], cs[2], cs[3], iters, d, sink);
+            hipDeviceSynchronize();
+        }
+        long long h[12];
+        hipMemcpy(h, d, 12 * 8, hipMemcpyDeviceToHost);
+        printf("%d waves/SIMD:", waves);
+        for (int s = 0; s < waves; ++s) {
+            const int r = cs[1 + s];
+            printf("  %-6s %7.1f cyc/iter (%d MFMA, %d VALU)", names[r], (double)h[4 * s] / iters, nm[r], nv[r]);
+        }
+        printf("\n");
+    }
+    return 0;
+}
