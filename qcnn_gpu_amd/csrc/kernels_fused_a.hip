@@ -1,11 +1,11 @@
 // Kernel A of the fused forward pass: Y -> I1.ppro -> C1 -> requant -> (C2_1 || C2_2) -> requant ->
 // concat, written to HBM as [H][W][48] int8 (see fused_common.h for the overall design).
 //
-// Persistent, wave-specialised: one 512-thread workgroup per CU walks a list of 16 x 32 output
+// Persistent, wave-specialised: one 768-thread workgroup per CU walks a list of 16 x 32 output
 // tiles.  Waves 0-3 are PRODUCERS (Y tile, im2col, C1 MFMAs, C1 requant epilogue: VALU-heavy),
-// waves 4-7 are CONSUMERS (C2 MFMAs, C2 requant epilogue: MFMA-heavy).  Wave w and wave w+4 share
-// a SIMD, so each SIMD always has one VALU-bound and one MFMA-bound instruction stream to
-// interleave.  The C1 tile is double-buffered in LDS; in step n the producers fill buffer n&1
+// waves 4-11 are CONSUMERS (C2 MFMAs, C2 requant epilogue: MFMA-heavy).  Waves w, w+4 and w+8 share
+// a SIMD, so each SIMD always has VALU-bound and MFMA-bound instruction streams to interleave: a
+// wave's own vector and matrix instructions barely overlap, those of different waves do.  The C1 tile is double-buffered in LDS; in step n the producers fill buffer n&1
 // with tile n while the consumers read buffer (n-1)&1; one workgroup barrier ends each step.
 // A workgroup walks its tiles DOWN a 32-pixel column of the frame: the top 4 rows of the C1 region
 // of a tile are the bottom 4 rows of the tile above it, so the producers copy them from the other
@@ -150,49 +150,15 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
     }
 }
 
-// One row of c2_store on the integer path: requant of row y of `acc` and its 12 bytes per lane.
-template <int ROWS>
-struct C2RowOut {
-    int8_t *out;       // the lane's 12 bytes of row 0
-    size_t row_bytes;
-    int rows_ok;       // rows of the block inside the frame
-    bool col_ok;       // the lane's column is inside the frame
-    __device__ __forceinline__ C2RowOut(int R0, int cb, int c, int g, int8_t *concf, int x0, int y0, int H, int W)
-    {
-        const int gx = x0 + cb + c, gy0 = y0 + R0;
-        row_bytes = (size_t)conc_wp(W) * 48;
-        out = concf + (size_t)(gy0 + 2) * row_bytes + (size_t)(gx + 2) * 48 + 12 * g;
-        rows_ok = H - gy0;
-        col_ok = gx < W;
-    }
-    __device__ __forceinline__ void store(const C2Acc<ROWS> &acc, int y, const C2Consts &k) const
-    {
-        unsigned d0, d1, d2;
-        requant12_int(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, d0, d1, d2);
-        if (y < rows_ok && col_ok) {
-            unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
-            dst[0] = d0;
-            dst[1] = d1;
-            dst[2] = d2;
-        }
-    }
-};
-
 // C2_1 (3x3, 64 -> 32) and C2_2 (5x5, 64 -> 16) for ROWS output rows x 16 columns of the tile in `buf`
 // (rows R0 .. R0+ROWS-1, columns cb .. cb+15) as 16x16x64 MFMAs into `acc`.  LDS row = output row + r,
 // LDS column = output column + s (the 3x3 taps are r-1, s-1 of the 5x5 window).  The LDS reads of
 // the first steps are issued, then `between()` runs (it may still read the previous contents of
 // `acc`), then the accumulators are set to the biases and the MFMA steps run.
-//
-// OVERLAP > 0 (integer path of the consumers): `acc` still holds the previous tile.  Column s = 0 of
-// the kernel walks the input rows top to bottom and step yy touches output rows <= yy only, so row yy
-// of the previous tile is handed to row_done(yy) (requant + store) right before step yy and its
-// accumulators restart from the biases; `between()` runs before step OVERLAP instead of before step 0.
-template <bool EXACT, int ROWS, int OVERLAP = 0, typename F, typename G = void (*)(int)>
+template <bool EXACT, int ROWS, typename F>
 __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *buf, int R0, int cb, int c, int g, const v4i *w22,
-                                        const v4i *w21, const C2Consts &k, F &&between, G &&row_done = nullptr)
+                                        const v4i *w21, const C2Consts &k, F &&between)
 {
-    static_assert(OVERLAP == 0 || (OVERLAP >= ROWS && OVERLAP < C2Plan<ROWS>::STEPS), "every row is handed over before the release");
     using namespace ka;
     using PO = C2PlanOf<ROWS>;  // PO::P is the plan
     constexpr int IN = C2Plan<ROWS>::IN, STEPS = C2Plan<ROWS>::STEPS;
@@ -212,34 +178,18 @@ __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *b
     };
     static_range<0, c2_issued<ROWS>(-1)>(issue);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (OVERLAP == 0) {
-        between();
-        __builtin_amdgcn_sched_barrier(0);
-        C2_STAMP();
+    between();
+    __builtin_amdgcn_sched_barrier(0);
+    C2_STAMP();
 #pragma unroll
-        for (int y = 0; y < ROWS; ++y) {
-            acc.a21[0][y] = k.b0;
-            acc.a21[1][y] = k.b1;
-            acc.a22[y] = k.b2;
-        }
+    for (int y = 0; y < ROWS; ++y) {
+        acc.a21[0][y] = k.b0;
+        acc.a21[1][y] = k.b1;
+        acc.a22[y] = k.b2;
     }
     static_for<STEPS>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
         constexpr int s = I / IN, yy = I % IN;
-        if constexpr (OVERLAP > 0) {
-            if constexpr (I < ROWS) {
-                row_done(I);
-                acc.a21[0][I] = k.b0;
-                acc.a21[1][I] = k.b1;
-                acc.a22[I] = k.b2;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (I == OVERLAP) {
-                between();
-                __builtin_amdgcn_sched_barrier(0);
-                C2_STAMP();
-            }
-        }
         static_range<c2_issued<ROWS>(I - 1), c2_issued<ROWS>(I)>(issue);
         const v4i B = item[PO::P.iB[s][yy]];
         static_for<5>([&](auto rc) {
@@ -266,15 +216,21 @@ __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *b
 #define C2_CONS_ROWS_N 8
 #endif
 constexpr int C2_CONS_ROWS = C2_CONS_ROWS_N;
-// MFMA steps of a tile that a consumer runs while it still requantises and stores the previous one
-// (with the producers parked at the barrier inside the step); 0 = store first, then all the MFMAs.
-// Measured on 1080p frames, us per frame of this kernel: 0: 75.6, 12: 77.2, 18: 79.6, 24: 80.6, 30:
-// 83.2 -- the producers' later start costs more than the consumers' MFMAs moved out of the shared phase
-// save, so the default stays 0.
-#ifndef C2_OVERLAP_N
-#define C2_OVERLAP_N 0
+// When the producer runs its share: 1 = at the start of the step, next to the consumer's requant + store phase;
+// 0 = at the end of the step, after its C1 work.
+#ifndef C2_SHARE_FIRST
+#define C2_SHARE_FIRST 1
 #endif
-constexpr int C2_OVERLAP = C2_OVERLAP_N;
+// Consumer waves per SIMD.  With two, consumer 0 takes the upper half of the SIMD's 8 x 16 block and stores a
+// tile at the start of the next step (as the single consumer does), consumer 1 takes the lower half and stores
+// at the end of its own step: one of them always has matrix instructions to issue while the other requantises.
+#ifndef C2_CONSUMERS_N
+#define C2_CONSUMERS_N 2
+#endif
+constexpr int C2_CONSUMERS = C2_CONSUMERS_N;
+static_assert(C2_CONSUMERS == 1 || (C2_CONSUMERS == 2 && C2_CONS_ROWS == 8), "two consumers split all 8 rows");
+constexpr int C2_ROWS = C2_CONS_ROWS / C2_CONSUMERS;      // rows of one consumer wave
+constexpr int A_WAVES = 4 + 4 * C2_CONSUMERS, A_THREADS = 64 * A_WAVES;
 
 // End of a pipeline step: every LDS write of this wave has landed, then the workgroup barrier.
 // (A raw s_barrier: global loads and stores in flight are deliberately not waited for.)
@@ -284,13 +240,20 @@ __device__ __forceinline__ void step_barrier()
 }
 // Barrier inside a step: the producers wait here until the consumers have stored their previous
 // tile, so that the two vector-heavy phases of a SIMD's wave pair do not run side by side.
+// (Not with two consumers per SIMD: the second one has matrix work from the start of the step.)
+#ifndef C2_MID_BARRIER
+#define C2_MID_BARRIER (C2_CONSUMERS_N == 1)
+#endif
 __device__ __forceinline__ void mid_barrier()
 {
+#if C2_MID_BARRIER
     asm volatile("s_barrier" ::: "memory");
+#endif
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
+__global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_waves_per_eu(A_WAVES / 4, A_WAVES / 4)))
+void k_c1c2(const FusedArgs a)
 {
     using namespace ka;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -333,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
     {
         const v4i *src = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C2W22);
         v4i *dst = reinterpret_cast<v4i *>(sW);
-        for (int i = tid; i < SW_BYTES / 16; i += 512) dst[i] = src[i];
+        for (int i = tid; i < SW_BYTES / 16; i += A_THREADS) dst[i] = src[i];
     }
 
     // C2 constants of this lane, used by the consumer and by the producer's share of the C2 rows
@@ -393,41 +356,44 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 bf1[i] = a.bias_f[32 + 16 * h + i];
             }
         }
-        // per-lane constants of the pixel groups k, for a cold tile (mode 0: region rows 5p .. 5p+4,
-        // 180 pixels, 6 groups) and for a warm tile (mode 1: rows 4+4p .. 7+4p, 144 pixels, 5 groups):
-        // LDS read address (k-group h = kernel rows 3h .. 3h+2), LDS
-        // write address, region coordinates
+        // per-lane constants of pixel group k, for a cold tile (mode 0: region rows 5p .. 5p+4, 180 pixels, 6
+        // groups) and for a warm tile (mode 1: rows 4+4p .. 7+4p, 144 pixels, 5 groups): LDS read address
+        // (k-group h = kernel rows 3h .. 3h+2), LDS write address, region coordinates.  Only the addresses of the
+        // warm tiles are kept in registers; cold tiles (the first of a workgroup and of a tile column) and the
+        // coordinates (frame-edge tiles only) are worked out where they are needed.
         constexpr int NKC = (PROD_ROWS * C1C + 31) / 32, NKW = (WARM_ROWS * C1C + 31) / 32;
-        int rd[2][NKC], wr[2][NKC], ij[2][NKC];
-        bool last_valid[2];
-#pragma unroll
-        for (int mode = 0; mode < 2; ++mode) {
+        auto group_consts = [&](int mode, int k, int &rdk, int &wrk, int &ijk, bool keep = false) {
             const int rows = mode ? WARM_ROWS : PROD_ROWS, row0 = mode ? 4 + WARM_ROWS * p : PROD_ROWS * p;
-            const int npix = rows * C1C, nk = mode ? NKW : NKC;
+            const int npix = rows * C1C;
+            int l = lane;
+            // (opaque to the compiler, or it would hoist the results out of the tile loop into registers again)
+            if (!keep) asm volatile("" : "+v"(l));
+            const int qi = k * 32 + (l & 31);
+            const int qc = qi < npix ? qi : npix - 1;
+            const int il = qc / C1C, j = qc - il * C1C;
+            const int cc = j & 3;
+            rdk = cc * YCOPY + (il + 3 * h) * YWS + (j - cc) + 4;
+            const int i = row0 + il;
+            wrk = (i * C1C + j) * 64 + swz(h, j);
+            ijk = i | (j << 8);
+        };
+        int rdw[NKW], wrw[NKW];
 #pragma unroll
-            for (int k = 0; k < NKC; ++k) {
-                const int qi = k * 32 + (lane & 31);
-                const int qc = qi < npix ? qi : npix - 1;
-                const int il = qc / C1C, j = qc - il * C1C;
-                const int cc = j & 3;
-                rd[mode][k] = cc * YCOPY + (il + 3 * h) * YWS + (j - cc) + 4;
-                const int i = row0 + il;
-                wr[mode][k] = (i * C1C + j) * 64 + swz(h, j);
-                ij[mode][k] = i | (j << 8);
-            }
-            last_valid[mode] = (nk - 1) * 32 + (lane & 31) < npix;
+        for (int k = 0; k < NKW; ++k) {
+            int unused;
+            group_consts(1, k, rdw[k], wrw[k], unused, true);
         }
+        const bool last_valid[2] = {(NKC - 1) * 32 + (lane & 31) < PROD_ROWS * C1C, (NKW - 1) * 32 + (lane & 31) < WARM_ROWS * C1C};
         constexpr int YLOADS = (9 * YWC + 63) / 64;  // bytes of the private Y tile per lane
-        // byte `it` of this lane: offset in the frame relative to the tile's first halo pixel, LDS
-        // offset in copy 0 (copy c sits c * (YCOPY - 1) further; -1: no byte), row | column << 8
-        int ywr[YLOADS], yrc[YLOADS];
-#pragma unroll
-        for (int it = 0; it < YLOADS; ++it) {
-            const int idx = it * 64 + lane;
-            const int row = idx / YWC, col = idx - row * YWC;
-            ywr[it] = idx < 9 * YWC ? row * YWS + col + 4 : -1;
-            yrc[it] = row | (col << 8);
-        }
+        // byte `it` of this lane (frame-edge tiles only): row and column relative to the tile's first halo pixel, LDS
+        // offset in copy 0 (copy c sits c * (YCOPY - 1) further; -1: no byte)
+        auto ybyte = [&](int it, int &row, int &col) {
+            int l = lane;
+            asm volatile("" : "+v"(l));  // (as above)
+            const int idx = it * 64 + l;
+            row = idx / YWC, col = idx - row * YWC;
+            return idx < 9 * YWC ? row * YWS + col + 4 : -1;
+        };
         // The same tile in one load, for tiles whose halo (and 3 bytes beyond it) lies inside the frame:
         // lane (row, j), j = 0..4, loads the 12 bytes 8j .. 8j+11 of tile row `row` and derives from them
         // dwords 2j and 2j+1 of all four copies (dword i of copy c holds columns 4i+c .. 4i+c+3 = a byte
@@ -453,7 +419,9 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
             } else {  // frame edge: clamped addresses; I1.ppro of the zero padding is (x - 128) == 0
 #pragma unroll
                 for (int it = 0; it < YLOADS; ++it) {
-                    const int gy = ya + (yrc[it] & 0xff), gx = xa + (yrc[it] >> 8);
+                    int yr, yc;
+                    ybyte(it, yr, yc);
+                    const int gy = ya + yr, gx = xa + yc;
                     const int cy = gy < 0 ? 0 : gy >= H ? H - 1 : gy, cx = gx < 0 ? 0 : gx >= W ? W - 1 : gx;
                     const unsigned char v = yf[(size_t)cy * W + cx];
                     ypre[it] = (cy == gy && cx == gx) ? (v ^ 0x80) : 0;
@@ -463,8 +431,24 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         TilePos nxt = pos, prev = pos;  // tiles n + 1 and n - 1 while tile n is computed
         if (N > 0) fetch_y(pos, false);
         advance(nxt);
+        // this wave's share of the C2 stage of tile n-1: the last rows of its consumer's block
+        auto c2_share = [&](int n) {
+            if constexpr (C2_CONS_ROWS < 8) {
+                if (n >= 1) {
+                    C2Acc<8 - C2_CONS_ROWS> acc;
+                    c2_mfma<EXACT, 8 - C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
+                                                     [] {});
+                    c2_store<EXACT, 8 - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
+                                                      a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
+                }
+            }
+        };
         for (int n = 0; n <= N; ++n) {
             STAMP();
+#if C2_SHARE_FIRST
+            // first, while the consumer of this SIMD requantises and stores (vector ALU only, matrix pipe idle)
+            c2_share(n);
+#endif
             mid_barrier();
             if (n < N) {
                 const int x0 = pos.tx * TW, y0 = pos.ty * TH;
@@ -483,9 +467,11 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                 } else {
 #pragma unroll
                     for (int it = 0; it < YLOADS; ++it) {
-                        if (ywr[it] >= 0) {
+                        int yr, yc;
+                        const int ywr = ybyte(it, yr, yc);
+                        if (ywr >= 0) {
 #pragma unroll
-                            for (int cc = 0; cc < 4; ++cc) sYw[ywr[it] + cc * (YCOPY - 1)] = ypre[it];
+                            for (int cc = 0; cc < 4; ++cc) sYw[ywr + cc * (YCOPY - 1)] = ypre[it];
                         }
                     }
                 }
@@ -499,7 +485,10 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                     auto c1_mfma = [&](int k, v16i &d0, v16i &d1) {
                         // rows 3h, 3h+1, 3h+2 of the window, 8 bytes each; the first 5 of each row are
                         // packed into 15 consecutive K positions (the 16th has zero weight)
-                        const unsigned *src = reinterpret_cast<const unsigned *>(sYw + rd[MODE][k]);
+                        int rdk, wrk, ijk;
+                        if constexpr (MODE) rdk = rdw[k];
+                        else group_consts(0, k, rdk, wrk, ijk);
+                        const unsigned *src = reinterpret_cast<const unsigned *>(sYw + rdk);
                         const unsigned r0l = src[0], r0h = src[1];
                         const unsigned r1l = src[YWS / 4], r1h = src[YWS / 4 + 1];
                         const unsigned r2l = src[YWS / 2], r2h = src[YWS / 2 + 1];
@@ -527,16 +516,20 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                             o1.z = quant4<true>(d1[8], d1[9], d1[10], d1[11], bf1[8], bf1[9], bf1[10], bf1[11], q);
                             o1.w = quant4<true>(d1[12], d1[13], d1[14], d1[15], bf1[12], bf1[13], bf1[14], bf1[15], q);
                         }
+                        int rdk, wrk, ijk;
+                        if constexpr (MODE) wrk = wrw[k];
+                        else group_consts(0, k, rdk, wrk, ijk);
                         if (edge) {
-                            const int gy = y0 - 2 + (ij[MODE][k] & 0xff), gx = x0 - 2 + (ij[MODE][k] >> 8);
+                            group_consts(MODE, k, rdk, wrk, ijk);
+                            const int gy = y0 - 2 + (ijk & 0xff), gx = x0 - 2 + (ijk >> 8);
                             if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) {
                                 o0 = v4i{0, 0, 0, 0};
                                 o1 = v4i{0, 0, 0, 0};
                             }
                         }
                         if (k + 1 < NK || last_valid[MODE]) {
-                            *reinterpret_cast<v4i *>(buf + wr[MODE][k]) = o0;         // channels 16h .. 16h+15
-                            *reinterpret_cast<v4i *>(buf + (wr[MODE][k] ^ 32)) = o1;  // channels 32+16h .. 32+16h+15
+                            *reinterpret_cast<v4i *>(buf + wrk) = o0;         // channels 16h .. 16h+15
+                            *reinterpret_cast<v4i *>(buf + (wrk ^ 32)) = o1;  // channels 32+16h .. 32+16h+15
                         }
                     };
                     // software pipeline: the MFMAs of group k+1 are in flight while group k is requantised
@@ -565,20 +558,15 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
                         if (i < PIECES) dst[i] = src[i];
                     }
                 }
+#ifndef QCNN_ABL_NOPRODUCE  // diagnostic builds only: the consumers alone (on whatever LDS holds)
                 if (warm) produce(std::integral_constant<int, 1>{});
                 else produce(std::integral_constant<int, 0>{});
+#endif
             }
             STAMP();
-            // this wave's share of the C2 stage of tile n-1: the last rows of its consumer's block
-            if constexpr (C2_CONS_ROWS < 8) {
-                if (n >= 1) {
-                    C2Acc<8 - C2_CONS_ROWS> acc;
-                    c2_mfma<EXACT, 8 - C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
-                                                     [] {});
-                    c2_store<EXACT, 8 - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
-                                                      a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
-                }
-            }
+#if !C2_SHARE_FIRST
+            c2_share(n);
+#endif
             if (n < N) {
                 prev = pos;
                 pos = nxt;
@@ -589,50 +577,60 @@ __global__ __launch_bounds__(512, 2) void k_c1c2(const FusedArgs a)
         }
     } else {
         // =============================== consumer ===============================
-        // the first C2_CONS_ROWS rows of the SIMD's 8 x 16 block of tile n-1
-        // In step n the wave issues the first LDS reads of tile n-1, requantises and stores tile n-2
-        // (whose accumulators it still holds) while they travel, then runs the MFMAs of tile n-1.
-        C2Acc<C2_CONS_ROWS> acc;
-        TilePos held = pos;  // the tile whose results `acc` holds
-        bool have = false;
-        auto store_held = [&] {
-            if (have)
-                c2_store<EXACT, C2_CONS_ROWS>(acc, R0, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
-                                              held.ty * TH, H, W);
-        };
-        auto store_then_release = [&] {
-            store_held();
-            mid_barrier();
-        };
-        for (int n = 0; n <= N; ++n) {
-            STAMP();
-            if (n >= 1) {
-                if constexpr (EXACT) {
-                    // the float pipeline needs its registers for the requant: results are stored at once
-                    c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
-                    c2_store<EXACT, C2_CONS_ROWS>(acc, R0, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
-                                                  pos.ty * TH, H, W);
-                } else {
-                    if constexpr (C2_OVERLAP > 0) {
-                        const C2RowOut<C2_CONS_ROWS> ro(R0, cb, c, g, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
-                                                        held.ty * TH, have ? H : 0, W);
-                        c2_mfma<EXACT, C2_CONS_ROWS, C2_OVERLAP>(
-                            acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, [] { mid_barrier(); },
-                            [&](int y) { ro.store(acc, y, kc); });
-                    } else {
-                        c2_mfma<EXACT, C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0, cb, c, g, w22, w21, kc, store_then_release);
-                    }
-                    held = pos;
-                    have = true;
-                }
-                advance(pos);
-            } else {
+        // rows R0c .. R0c + C2_ROWS - 1 of the SIMD's 8 x 16 block of tile n-1.
+        // A deferring consumer, in step n, issues the first LDS reads of tile n-1, requantises and stores tile
+        // n-2 (whose accumulators it still holds) while they travel, then runs the MFMAs of tile n-1.  The second
+        // consumer of a SIMD (and the float pipeline, which needs its registers for the requant) stores a tile
+        // right after its MFMAs.
+        auto consumer = [&](auto deferc, int half) {
+            constexpr bool DEFER = decltype(deferc)::value;
+            const int R0c = R0 + half * C2_ROWS;
+            C2Acc<C2_ROWS> acc;
+            TilePos held = pos;  // the tile whose results `acc` holds
+            bool have = false;
+            auto store_held = [&] {
+                if (have)
+                    c2_store<EXACT, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
+                                             held.ty * TH, H, W);
+            };
+            auto store_then_release = [&] {
+                store_held();
                 mid_barrier();
+            };
+            for (int n = 0; n <= N; ++n) {
+                STAMP();
+                if (n >= 1) {
+#ifdef QCNN_ABL_NOCONSUME  // diagnostic builds only: the producers alone
+                    mid_barrier();
+#else
+                    const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
+                    if constexpr (DEFER) {
+                        c2_mfma<EXACT, C2_ROWS>(acc, buf, R0c, cb, c, g, w22, w21, kc, store_then_release);
+                        held = pos;
+                        have = true;
+                    } else {
+                        c2_mfma<EXACT, C2_ROWS>(acc, buf, R0c, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
+                        c2_store<EXACT, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
+                                                 pos.ty * TH, H, W);
+                    }
+#endif
+                    advance(pos);
+                } else {
+                    mid_barrier();
+                }
+                STAMP();
+                step_barrier();
             }
-            STAMP();
-            step_barrier();
+            if constexpr (DEFER) store_held();
+        };
+        if constexpr (EXACT) {
+            consumer(std::false_type{}, (wv - 4) >> 2);
+        } else if constexpr (C2_CONSUMERS == 1) {
+            consumer(std::true_type{}, 0);
+        } else {
+            if (wv < 8) consumer(std::true_type{}, 0);
+            else consumer(std::false_type{}, 1);
         }
-        store_held();
     }
 }
 
@@ -642,8 +640,8 @@ hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s)
     if (ntiles < 1) return hipSuccess;
     const int ncu = a.ncu > 0 ? a.ncu : 256;
     dim3 grid(ntiles < ncu ? ntiles : ncu);
-    if (exact) hipLaunchKernelGGL(k_c1c2<true>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(k_c1c2<false>, grid, dim3(512), 0, s, a);
+    if (exact) hipLaunchKernelGGL(k_c1c2<true>, grid, dim3(A_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_c1c2<false>, grid, dim3(A_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -47,7 +47,8 @@ __device__ __forceinline__ int lane_of_pixel(int pix, int g)
 
 // Cache policy bits of the conc1 loads.  conc1 is read once (apart from the four columns two neighbouring strips
 // share): the non-temporal hint takes 8 % off the kernel, the scope bits sc0 / sc1 change nothing (measured;
-// experiment builds pick another policy with -DQCNN_CONC_LOAD_POLICY=n).  The same hint on the Y loads and the
+// experiment builds pick another policy with -DQCNN_CONC_LOAD_POLICY=n; neither does keeping the shared columns
+// as ordinary loads in an instruction of their own: 28.6 against 26.9 us per 1080p frame).  The same hint on the Y loads and the
 // byte stores of the output costs 16 %: their lines are shared by neighbouring strips and rows.
 #ifndef QCNN_CONC_LOAD_POLICY
 #define QCNN_CONC_LOAD_POLICY 1
@@ -155,6 +156,7 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     const int lane16 = lane * 16;
     const int y_voff = (lane < SW && x0 + lane < W) ? lane : OOB;
     const unsigned long long row_lanes = (1ull << (ROW_BYTES / 16)) - 1;
+
     const unsigned ring_s = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);  // LDS byte addresses
     const unsigned yring_s = ring_s + RING_BYTES;
     // requests conc1 row `crow` of the bordered image and the Y pixels of output row `yrow` into ring slot

@@ -19,9 +19,10 @@ sys.path.insert(0, %(root)r)
 from qcnn_gpu_amd import capi, synth
 capi.LIB_PATH = os.path.join(%(root)r, "qcnn_gpu_amd", %(lib)r, "libqcnn.so")
 from qcnn_gpu_amd.qvrcnn import qvrcnn
-h, w, qp, B = 1080, 1920, 37, 16
+h, w, qp, B = (2160, 3840, 32, 5) if os.environ.get("AB_4K") else (1080, 1920, 37, 16)
 lib = capi.load()
 net = qvrcnn(0, 1, 1, h, w)
+if os.environ.get("AB_EXACT"): net.set_exact(True)
 net.load_static_para(synth.synth_model(qp).to_nchw_vect_c_bytes())
 anc = synth.synth_frames(h, w, qp, frames=4)[1]
 d_in, d_out = C.c_void_p(), C.c_void_p()
