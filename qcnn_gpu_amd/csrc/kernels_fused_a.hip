@@ -109,6 +109,9 @@ template <bool EXACT, int ROWS>
 __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb, int c, int g, const C2Consts &k, int8_t *concf,
                                          int x0, int y0, int H, int W)
 {
+#ifdef QCNN_ABL_L2STORES  // diagnostic builds only (garbage results): every workgroup keeps storing one tile, which stays in L2
+    x0 = (blockIdx.x % 60) * ka::TW, y0 = (blockIdx.x / 60) * ka::TH;
+#endif
     const int gx = x0 + cb + c, gy0 = y0 + R0;
     // the frame sits at rows / columns 2.. of the bordered conc1 image
     const size_t row_bytes = (size_t)conc_wp(W) * 48;  // row y sits y * row_bytes further

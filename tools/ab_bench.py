@@ -40,6 +40,9 @@ out = np.empty(B * h * w, np.uint8); capi.check(lib.qcnn_dev_d2h(out.ctypes.data
 print("%%-10s k_c1c2 %%7.1f us/frame  k_c3c4 %%7.1f us/frame  total %%8.1f Mpx/s  crc32(out) %%08x" %% (%(lib)r, ka / B, kb / B, 20 * B * h * w / dt / 1e6, zlib.crc32(out.tobytes())))
 """
 
+if len(sys.argv) == 3 and sys.argv[1] == "--inline":  # this process itself (for use under rocprofv3)
+    exec(CHILD % {"root": ROOT, "lib": sys.argv[2]})
+    sys.exit(0)
 for name in sys.argv[1:] or ["lib"]:
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "lib": name}], capture_output=True, text=True, timeout=300)
     sys.stdout.write(r.stdout if r.returncode == 0 else f"{name}: FAILED\n{r.stderr[-2000:]}\n")
