@@ -236,6 +236,36 @@ def test_batch_of_frames_any_group(group):
     capi.check(lib.qcnn_dev_free(d_out))
 
 
+def test_batch_calls_back_to_back():
+    """Batch calls of several groups each, queued back to back on two pairs of buffers without a synchronisation
+    in between: every call reuses the conc1 image of the one before it."""
+    qp, h, w, nf = 32, 70, 123, 9
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    fa = synth.synth_frames(h, w, qp, frames=nf, seed=5)[1]
+    fb = synth.synth_frames(h, w, qp, frames=nf, seed=6)[1]
+    lib = capi.load()
+    bufs = [C.c_void_p() for _ in range(4)]
+    for b in bufs:
+        capi.check(lib.qcnn_dev_alloc(C.byref(b), nf * h * w))
+    for src, dst in ((fa, bufs[0]), (fb, bufs[1])):
+        f = np.ascontiguousarray(src)
+        capi.check(lib.qcnn_dev_h2d(dst, f.ctypes.data, nf * h * w))
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        net.batch_group(2)
+        for _ in range(3):
+            net.forward_blu_batch(bufs[0].value, bufs[2].value, nf, h * w)
+            net.forward_blu_batch(bufs[1].value, bufs[3].value, nf, h * w)
+        net.synchronize()
+        for src, dst in ((fa, bufs[2]), (fb, bufs[3])):
+            out = np.empty((nf, h, w), np.uint8)
+            capi.check(lib.qcnn_dev_d2h(out.ctypes.data, dst, nf * h * w))
+            for i in range(nf):
+                assert np.array_equal(out[i], c_oracle.forward_blu(mb, np.ascontiguousarray(src[i]))), f"frame {i}"
+    for b in bufs:
+        capi.check(lib.qcnn_dev_free(b))
+
+
 @pytest.mark.parametrize("group", [1, 3, 16])
 def test_host_clip_pipeline(group):
     """qcnn_forward_blu_clip: the H2D + forward_blu + D2H loop of inference/kernel.cu:89-101 as a pipeline,
