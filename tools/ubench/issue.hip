@@ -101,5 +101,25 @@ int main(int argc, char **argv)
         }
         printf("\n");
     }
+    // sustained rate of the matrix pipe alone: three MFMA waves per SIMD on every CU for about ten milliseconds
+    {
+        const int it2 = 40000;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k, dim3(256), dim3(768), 0, 0, 1, 1, 1, it2, d, sink);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            long long h[12];
+            hipMemcpy(h, d, 12 * 8, hipMemcpyDeviceToHost);
+            const double mfmas = 256.0 * 12 * 16 * it2, ops = mfmas * 2 * 16 * 16 * 64;
+            printf("MFMA only, 12 waves per CU: %.2f ms, %.2f POP/s int8, slowest wave %.0f cycles -> %.2f GHz shader clock\n", ms,
+                   ops / ms / 1e12, (double)h[8], h[8] / (ms * 1e6));
+        }
+    }
     return 0;
 }
