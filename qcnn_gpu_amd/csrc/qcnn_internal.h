@@ -23,8 +23,8 @@ struct Requant {
 };
 
 // ---- fused kernel geometry -------------------------------------------------------------
-// Kernel A: Y -> C1 -> (C2_1 || C2_2) -> conc1 in HBM.  Persistent 512-thread workgroups walk
-// 16 x 32 output tiles; four producer waves fill a double-buffered C1 tile, four consumer waves
+// Kernel A: Y -> C1 -> (C2_1 || C2_2) -> conc1 in HBM.  Persistent 768-thread workgroups walk
+// 16 x 32 output tiles; four producer waves fill a double-buffered C1 tile, eight consumer waves
 // run the C2 stage on the other buffer.
 namespace ka {
 constexpr int TH = 16, TW = 32;
