@@ -200,6 +200,35 @@ def test_4k_frame_qp32_bit_exact():
         capi.check(lib.qcnn_dev_free(d_out))
 
 
+def test_8k_frame_windows_equal_their_crops():
+    """The largest frame the engine takes to within a row (7680x4320: conc1 offsets up to 1.6e9, under the 2^31 the
+    buffer descriptors allow) through the size-independent property that every output pixel depends on a 13x13
+    neighbourhood only (5x5, 5x5, 3x3, 3x3): windows of the 8K result equal the oracle's result on the window
+    grown by 6 pixels (cut at the frame edges, where the zero padding is the frame's own)."""
+    qp, h, w = 37, 4320, 7680
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    rng = np.random.default_rng(8192)
+    frame = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        net.load_data(frame)
+        net.forward_blu()
+        rec = net.download()
+    m = 6
+    for y0, x0, hh, ww in [(0, 0, 150, 200), (h - 170, w - 210, 170, 210), (2000, 3700, 128, 300), (h - 90, 0, 90, 120),
+                           (0, w - 100, 75, 100), (4000, 7000, 64, 64)]:
+        ya, yb, xa, xb = max(y0 - m, 0), min(y0 + hh + m, h), max(x0 - m, 0), min(x0 + ww + m, w)
+        crop = np.ascontiguousarray(frame[ya:yb, xa:xb])
+        ref = c_oracle.forward_blu(mb, crop)
+        # interior of the crop: everything at least 6 pixels from a cut that is not a frame edge
+        ia = 0 if ya == 0 else m
+        ib = (yb - ya) if yb == h else (yb - ya) - m
+        ja = 0 if xa == 0 else m
+        jb = (xb - xa) if xb == w else (xb - xa) - m
+        got = rec[ya + ia:ya + ib, xa + ja:xa + jb]
+        assert np.array_equal(got, ref[ia:ib, ja:jb]), f"window at ({y0}, {x0})"
+
+
 @pytest.mark.parametrize("group", [1, 3, 16])
 def test_batch_of_frames_any_group(group):
     """The frame loop of inference/kernel.cu:91-97 on resident frames: 7 distinct frames with a
