@@ -231,6 +231,33 @@ constexpr int C2_CONS_ROWS = C2_CONS_ROWS_N;
 #define C2_CONSUMERS_N 2
 #endif
 constexpr int C2_CONSUMERS = C2_CONSUMERS_N;
+// Which of the two consumers of a SIMD keeps its accumulators over the step boundary (requantises and stores first,
+// then runs its matrix instructions): 0 = the older wave (4..7), 1 = the younger one (8..11).
+#ifndef C2_DEFER_YOUNGER
+#define C2_DEFER_YOUNGER 1
+#endif
+// Experiment: wave priorities (s_setprio) of a consumer in its matrix phase and in its requant + store phase, per
+// role (D = the deferring consumer, N = the other one); -1 = leave the priority alone.  Producers stay at 0.
+#ifndef C2_PRIO_D_MFMA
+#define C2_PRIO_D_MFMA -1
+#endif
+#ifndef C2_PRIO_D_VALU
+#define C2_PRIO_D_VALU -1
+#endif
+#ifndef C2_PRIO_N_MFMA
+#define C2_PRIO_N_MFMA -1
+#endif
+#ifndef C2_PRIO_N_VALU
+#define C2_PRIO_N_VALU -1
+#endif
+#ifndef C2_PRIO_PRODUCER
+#define C2_PRIO_PRODUCER -1
+#endif
+template <int P>
+__device__ __forceinline__ void set_prio()
+{
+    if constexpr (P >= 0) asm volatile("s_setprio %0" ::"n"(P));
+}
 static_assert(C2_CONSUMERS == 1 || (C2_CONSUMERS == 2 && C2_CONS_ROWS == 8), "two consumers split all 8 rows");
 constexpr int C2_ROWS = C2_CONS_ROWS / C2_CONSUMERS;      // rows of one consumer wave
 constexpr int A_WAVES = 4 + 4 * C2_CONSUMERS, A_THREADS = 64 * A_WAVES;
@@ -342,6 +369,7 @@ void k_c1c2(const FusedArgs a)
         // K positions with four byte permutes; the 16th position and kernel rows >= 5 have zero
         // weights, so whatever those bytes hold is multiplied by zero.
         const int p = wv;
+        set_prio<C2_PRIO_PRODUCER>();
         unsigned char *sYw = sYall + p * SYW_BYTES;  // [4][YWR][YWS] int8 (x - 128), 0 outside the frame
         const v4i *wp = reinterpret_cast<const v4i *>(a.wpack + PackedOffsets::C1W) + lane;
         const v4i A0 = wp[0], A1 = wp[64];  // one fragment per 32-channel tile
@@ -599,6 +627,7 @@ void k_c1c2(const FusedArgs a)
             auto store_then_release = [&] {
                 store_held();
                 mid_barrier();
+                set_prio<C2_PRIO_D_MFMA>();
             };
             for (int n = 0; n <= N; ++n) {
                 STAMP();
@@ -609,10 +638,13 @@ void k_c1c2(const FusedArgs a)
                     const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
                     if constexpr (DEFER) {
                         c2_mfma<EXACT, C2_ROWS>(acc, buf, R0c, cb, c, g, w22, w21, kc, store_then_release);
+                        set_prio<C2_PRIO_D_VALU>();
                         held = pos;
                         have = true;
                     } else {
+                        set_prio<C2_PRIO_N_MFMA>();
                         c2_mfma<EXACT, C2_ROWS>(acc, buf, R0c, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
+                        set_prio<C2_PRIO_N_VALU>();
                         c2_store<EXACT, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
                                                  pos.ty * TH, H, W);
                     }
@@ -631,8 +663,13 @@ void k_c1c2(const FusedArgs a)
         } else if constexpr (C2_CONSUMERS == 1) {
             consumer(std::true_type{}, 0);
         } else {
+#if C2_DEFER_YOUNGER
+            if (wv < 8) consumer(std::false_type{}, 0);
+            else consumer(std::true_type{}, 1);
+#else
             if (wv < 8) consumer(std::true_type{}, 0);
             else consumer(std::false_type{}, 1);
+#endif
         }
     }
 }

@@ -21,7 +21,7 @@
 // MFMA and vector phases interleave as the hardware schedules them.  Zero padding: conc1 comes with a
 // border of zeros in HBM (qcnn_internal.h, conc_bytes), conc2 pixels outside the frame are zeroed in
 // registers.
-#define STAMP_ROW (wv + 8)  // diagnostic builds: rows 8..11 of the stamp buffer (kernel A owns 0..7)
+#define STAMP_ROW (wv + 12)  // diagnostic builds: rows 12..15 of the stamp buffer (kernel A owns 0..11)
 #include "fused_common.h"
 
 namespace qcnn {
