@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--group", type=int, default=0, help="frames per kernel launch (0 = engine default)")
     ap.add_argument("--prewarm", type=float, default=2.0, help="seconds of untimed launches before the warm-up steps")
     ap.add_argument("--exact", action="store_true",
-                    help="force the float-pipeline kernels (what a model that fails the integer-path proof runs on)")
+                    help="force the float-pipeline kernels (what a model with out-of-range parameters runs on)")
+    ap.add_argument("--wide", action="store_true",
+                    help="force kernel A's clamped integer form (what a model whose C2 accumulator bounds pass 2^24 runs on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-shared-gpus", action="store_true",
                     help="let ranks share a device when fewer than --gpus are present (rehearsal only)")
@@ -156,8 +158,8 @@ def main():
     nsrc = min(B, 4)
     _, anc = synth.synth_frames(h, w, qp, frames=nsrc, seed=0x51434E4E + rank)
     net = qvrcnn(dev, 1, 1, h, w)
-    if a.exact:
-        net.set_exact(True)
+    if a.exact or a.wide:
+        net.set_exact(1 if a.exact else 2)
     net.load_static_para(mb)
     fpl = min(net.batch_group(a.group), B)      # frames one launch of each fused kernel covers
     d_in, d_out = C.c_void_p(), C.c_void_p()
@@ -282,7 +284,8 @@ def main():
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": f"{shape_tag}: {w}x{h} Y frame, QP{qp} int8, frames resident in HBM",
                        "frames_per_step_per_gpu": B, "frames_per_launch": fpl, "frame": [h, w], "qp": qp,
-                       "epilogue": "float pipeline (EXACT)" if net.is_exact else "integer (proved at load)",
+                       "epilogue": {(0, 0): "integer (proved at load)", (2, 0): "integer, C2 accumulators clamped first"}.get(
+                           net.arith_paths, "float pipeline (EXACT)"),
                        "devices_present": ndev.value, "prewarm_s": a.prewarm,
                        "sharding": f"frames over {world} GPU(s), no collective"},
             "roofline": {"bound": "mfma", "kernel": "k_c1c2 (I1.ppro + C1 + C2_1 + C2_2 + concat)",

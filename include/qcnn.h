@@ -237,11 +237,16 @@ void *qcnn_layer_w_device_ptr(qcnn_t *e, int layer);
 void *qcnn_layer_b_device_ptr(qcnn_t *e, int layer);
 void *qcnn_layer_b_adj_device_ptr(qcnn_t *e, int layer);
 
-/* Arithmetic of the fused kernels.  At every load the engine proves from the weights whether the
- * reference's float32 accumulator pipeline (inference/cnn.cu:148-155, inference/mat.cu:275-291)
- * is identical to integer arithmetic (all |acc|, |bias| < 2^24) and then uses integer epilogues;
- * otherwise it replays the float32 pipeline literally.  qcnn_set_exact(e, 1) forces the literal
- * pipeline from the next load on; qcnn_is_exact reports which one the loaded model uses. */
+/* Arithmetic of the fused kernels.  At every load the engine proves from the weights, per layer, whether
+ * the reference's float32 accumulator pipeline (inference/cnn.cu:148-155, inference/mat.cu:275-291)
+ * is identical to integer arithmetic (all |acc|, |bias| < 2^24, requantiser operands inside 24 bits) and
+ * then uses integer epilogues.  The two fused kernels choose separately: kernel A (C1, C2_1, C2_2) runs
+ * 0 = integer epilogues, 2 = integer epilogues with the C2 accumulators clamped first (a model whose C2
+ * accumulator bounds alone fail the proof; one more instruction per value), or 1 = the float32 pipeline
+ * replayed literally; kernel B (C3_1, C3_2, C4) runs 0 or 1.  qcnn_is_exact returns
+ * path of kernel A | path of kernel B << 4 (0 = plain integers everywhere).  qcnn_set_exact(e, 1) forces the
+ * literal pipeline in both kernels from the next load on, qcnn_set_exact(e, 2) the clamped form of kernel A
+ * for a model that qualifies for plain integers, qcnn_set_exact(e, 0) returns to the proof's choice. */
 int qcnn_set_exact(qcnn_t *e, int on);
 int qcnn_is_exact(qcnn_t *e);
 /* The engine's hipStream_t (as void*), for callers that enqueue their own work behind it. */

@@ -120,8 +120,9 @@ struct qcnn_engine {
     float *f_b[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // model
     bool loaded = false;
-    bool exact = false;  // true: float-pipeline kernels; false: integer fast path proved safe
-    int force_exact = 0;
+    // arithmetic of the two fused kernels for the loaded model (PATH_INT / PATH_FLOAT / PATH_WIDE, see prove_paths)
+    int path_a = 0, path_b = 0;
+    int force_exact = 0;  // 1: float pipeline in both kernels, 2: clamped integers in kernel A (test / bench hooks)
     Requant rq[6];
     // clip pipeline (qcnn_forward_blu_clip): copy streams, two-deep device rings, hand-off events
     hipStream_t s_in = nullptr, s_out = nullptr, s_ori = nullptr;
@@ -323,49 +324,69 @@ static void acc_range(const LayerView &L, int l, int k, long long *lo, long long
     *lo = pos * in_lo - neg * in_hi;
 }
 
-// Decides whether the integer fast path reproduces the reference's float32 pipeline for THIS
-// model.  With every |acc| and |bias| at most 2^24 the conversions to float are exact, and with
+// Decides, per layer, whether integer epilogues reproduce the reference's float32 pipeline for THIS model.
+// With every |acc| and |bias| at most 2^24 the conversions to float are exact, and with
 // s = acc + bias + rounding offset of the requantiser (which the integer path adds to the bias) inside
 // [-2^23, 2^23) the float sum is exact too and s is a signed 24-bit operand of the requantiser's
 // multiply; with requant(blu) == 127 the clip-to-127 arm equals requantising min(u, blu), and the
-// saturating 32-bit product (see requant4_int) keeps byte 3 at 127 beyond it.
-static bool prove_integer_path(const LayerView L[6], const Requant rq[6])
+// saturating 32-bit product (see requant4_int) keeps byte 3 at 127 beyond it: PATH_INT.
+// If only the accumulator bounds fail, s can still be clamped to [-1, blu + rounding offset] first (one more
+// instruction per value, fused_common.h requant12_wide): every s above that limit requantises to 127 like blu
+// itself, every negative one to 0, and an accumulator beyond 2^24 (where the conversion to float rounds to an even
+// integer) is, with |bias| <= 2^23, at least 2^23 away from both thresholds on the same side before and after
+// rounding: PATH_WIDE.  Anything else gets the literal float pipeline: PATH_FLOAT.
+enum { PATH_INT = 0, PATH_FLOAT = 1, PATH_WIDE = 2 };
+static int prove_layer_path(const LayerView &L, int l, const Requant &q)
 {
     const long long LIM24 = 1ll << 24, LIM23 = 1ll << 23;
-    for (int l = 0; l < 5; ++l) {
-        const Requant &q = rq[l];
-        if (q.blu < 0 || q.mul <= 0 || q.shift > 24 || q.bias < 0) return false;
-        for (int k = 0; k < L[l].cout; ++k) {
-            long long lo, hi;
-            acc_range(L[l], l, k, &lo, &hi);
-            const long long b = L[l].b[k];
-            if (-lo > LIM24 || hi > LIM24 || std::llabs(b) > LIM24) return false;
-            if (lo + b + q.bias < -LIM23 || hi + b + q.bias >= LIM23) return false;
-        }
-        if ((long long)q.blu + q.bias >= LIM23) return false;
+    if (l < 5) {
+        if (q.blu < 0 || q.mul <= 0 || q.shift > 24 || q.bias < 0) return PATH_FLOAT;
+        if ((long long)q.blu + q.bias >= LIM23) return PATH_FLOAT;
         const long long top = ((long long)(q.blu + q.bias) * q.mul) >> q.shift;
-        if (top != 127) return false;  // also bounds (blu + bias) * mulk below 128 << 24 = 2^31
+        if (top != 127) return PATH_FLOAT;  // also bounds (blu + bias) * mulk below 128 << 24 = 2^31
         // pre-shifted multiplier: a positive signed 24-bit operand; bias * mulk <= 2^23
-        if (((long long)q.mul << (24 - q.shift)) >= LIM23) return false;
+        if (((long long)q.mul << (24 - q.shift)) >= LIM23) return PATH_FLOAT;
+        int path = PATH_INT;
+        for (int k = 0; k < L.cout; ++k) {
+            long long lo, hi;
+            acc_range(L, l, k, &lo, &hi);
+            const long long b = L.b[k];
+            if (std::llabs(b) > LIM24) return PATH_FLOAT;
+            if (-lo > LIM24 || hi > LIM24 || lo + b + q.bias < -LIM23 || hi + b + q.bias >= LIM23) {
+                // the accumulator itself always fits an int (at most 1600 taps of 127 x 128)
+                if (std::llabs(b) > LIM23 || -lo >= (1ll << 30) || hi >= (1ll << 30)) return PATH_FLOAT;
+                path = PATH_WIDE;
+            }
+        }
+        return path;
     }
     // C4 + applyRes_y in integers: acc + bias and the multiplier are 24-bit operands, the product plus
     // the rounding term stays below 2^31 (so the reference's unsigned arithmetic does not wrap), and
     // pixel + residual fits the reference's short
-    {
-        const Requant &q = rq[5];
-        long long lo, hi;
-        acc_range(L[5], 5, 0, &lo, &hi);
-        const long long b = L[5].b[0];
-        if (-lo > LIM24 || hi > LIM24 || std::llabs(b) > LIM24) return false;
-        const long long top = std::max(std::llabs(lo + b), std::llabs(hi + b));
-        if (top >= LIM23 || q.mul <= 0 || q.mul >= (1 << 23)) return false;
-        // the streaming kernel multiplies the accumulator without its bias (the bias rides in the rounding constant)
-        if (-lo >= LIM23 || hi >= LIM23 || std::llabs(b) * q.mul + (1ll << (q.shift - 1)) >= (1ll << 31)) return false;
-        const long long prod = top * q.mul + (1ll << (q.shift - 1));
-        if (prod >= (1ll << 31)) return false;
-        if ((prod >> q.shift) + 255 >= 32767) return false;
-    }
-    return true;
+    long long lo, hi;
+    acc_range(L, 5, 0, &lo, &hi);
+    const long long b = L.b[0];
+    if (-lo > LIM24 || hi > LIM24 || std::llabs(b) > LIM24) return PATH_FLOAT;
+    const long long top = std::max(std::llabs(lo + b), std::llabs(hi + b));
+    if (top >= LIM23 || q.mul <= 0 || q.mul >= (1 << 23)) return PATH_FLOAT;
+    // the streaming kernel multiplies the accumulator without its bias (the bias rides in the rounding constant)
+    if (-lo >= LIM23 || hi >= LIM23 || std::llabs(b) * q.mul + (1ll << (q.shift - 1)) >= (1ll << 31)) return PATH_FLOAT;
+    const long long prod = top * q.mul + (1ll << (q.shift - 1));
+    if (prod >= (1ll << 31)) return PATH_FLOAT;
+    if ((prod >> q.shift) + 255 >= 32767) return PATH_FLOAT;
+    return PATH_INT;
+}
+
+// Kernel A (C1, C2_1, C2_2) and kernel B (C3_1, C3_2, C4) choose their arithmetic separately.  Kernel A has the
+// clamped form for its C2 stage only (C1's 25 taps cannot leave the 24-bit range); kernel B's accumulators
+// (at most 432 taps of 127 x 127) cannot either, so it knows the integer and the float form only.
+static void prove_paths(const LayerView L[6], const Requant rq[6], int *path_a, int *path_b)
+{
+    int p[6];
+    for (int l = 0; l < 6; ++l) p[l] = prove_layer_path(L[l], l, rq[l]);
+    if (p[0] != PATH_INT || p[1] == PATH_FLOAT || p[2] == PATH_FLOAT) *path_a = PATH_FLOAT;
+    else *path_a = (p[1] == PATH_WIDE || p[2] == PATH_WIDE) ? PATH_WIDE : PATH_INT;
+    *path_b = (p[3] == PATH_INT && p[4] == PATH_INT && p[5] == PATH_INT) ? PATH_INT : PATH_FLOAT;
 }
 
 static int load_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
@@ -396,15 +417,17 @@ static int load_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
     }
     std::vector<int8_t> packed;
     pack_fragments(L, packed);
-    e->exact = e->force_exact ? true : !prove_integer_path(L, e->rq);
+    prove_paths(L, e->rq, &e->path_a, &e->path_b);
+    if (e->force_exact == 1) e->path_a = e->path_b = PATH_FLOAT;
+    else if (e->force_exact == 2 && e->path_a == PATH_INT) e->path_a = PATH_WIDE;
     // make sure no kernel of a previous forward pass still reads the old parameters
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->wpack, packed.data(), packed.size(), hipMemcpyHostToDevice));
     {
-        // the integer path starts its accumulators from bias + rounding offset of the requantiser
+        // the integer paths start their accumulators from bias + rounding offset of the requantiser
         std::vector<int32_t> start(bias_i);
-        if (!e->exact)
-            for (int l = 0; l < 5; ++l)
+        for (int l = 0; l < 5; ++l)
+            if ((l < 3 ? e->path_a : e->path_b) != PATH_FLOAT)
                 for (int k = 0; k < L_COUT[l]; ++k) start[BIAS_OFF[l] + k] += e->rq[l].bias;
         HIP_TRY(hipMemcpy(e->bias_i, start.data(), 161 * sizeof(int), hipMemcpyHostToDevice));
     }
@@ -583,7 +606,7 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
         e->tiled_b = tb && atoi(tb) != 0;
     }
     const char *fx = getenv("QCNN_FORCE_EXACT");
-    e->force_exact = fx && atoi(fx) != 0;
+    e->force_exact = fx ? atoi(fx) : 0;
     *out = e;
     return QCNN_OK;
 }
@@ -660,13 +683,19 @@ int qcnn_load_static(qcnn_t *e, const char *path)
 
 int qcnn_set_exact(qcnn_t *e, int on)
 {
-    // test hook: force the float-pipeline kernels (takes effect at the next load)
+    // test hook (takes effect at the next load): 1 forces the float-pipeline kernels, 2 the clamped integer form
+    // of kernel A for a model that would run the plain integer form
     if (!e) return fail(QCNN_E_ARG, "null engine");
-    e->force_exact = on != 0;
+    if (on < 0 || on > 2) return fail(QCNN_E_ARG, "qcnn_set_exact: mode %d", on);
+    e->force_exact = on;
     return QCNN_OK;
 }
 
-int qcnn_is_exact(qcnn_t *e) { return e ? (e->exact ? 1 : 0) : fail(QCNN_E_ARG, "null engine"); }
+int qcnn_is_exact(qcnn_t *e)
+{
+    if (!e) return fail(QCNN_E_ARG, "null engine");
+    return e->path_a | (e->path_b << 4);
+}
 
 int qcnn_upload(qcnn_t *e, const uint8_t *host_y)
 {
@@ -707,10 +736,10 @@ static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nfr
         }
     }
     if (ev) HIP_TRY(hipEventRecord(ev[0], e->stream));
-    HIP_TRY(launch_fused_c1c2(a, e->exact, e->stream));
+    HIP_TRY(launch_fused_c1c2(a, e->path_a, e->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], e->stream));
-    if (e->tiled_b) HIP_TRY(launch_fused_c3c4(a, e->exact, e->stream));
-    else HIP_TRY(launch_fused_c3c4_stream(a, e->exact, e->stream));
+    if (e->tiled_b) HIP_TRY(launch_fused_c3c4(a, e->path_b == PATH_FLOAT, e->stream));
+    else HIP_TRY(launch_fused_c3c4_stream(a, e->path_b == PATH_FLOAT, e->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[2], e->stream));
     return QCNN_OK;
 }

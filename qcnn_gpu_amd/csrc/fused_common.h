@@ -14,11 +14,12 @@
 // output rows, and keeps the A fragments of one kernel column in registers while it sweeps the
 // input rows; that is what holds LDS and L1 traffic per MFMA low.
 //
-// Two instantiations of each kernel exist.  EXACT=false is used when the host has proved, from
-// the loaded weights, that no accumulator or bias can reach 2^24: then the reference's float32
-// pipeline (float(acc) + float(b), float compares, (int) truncation) is identical to integer
-// arithmetic and the bias is folded into the MFMA accumulator.  EXACT=true replays the float32
-// pipeline literally and is bit-exact for every possible model.
+// Each kernel exists in an integer and in a float-pipeline instantiation.  The integer one is used when the
+// host has proved, from the loaded weights, that no accumulator or bias can reach 2^24: then the reference's
+// float32 pipeline (float(acc) + float(b), float compares, (int) truncation) is identical to integer
+// arithmetic and the bias is folded into the MFMA accumulator.  The float-pipeline one (EXACT) replays the
+// float32 pipeline literally and is bit-exact for every possible model.  Kernel A has a third instantiation
+// for models whose C2 accumulator bounds alone fail the proof (requant12_wide): integers with one clamp more.
 #pragma once
 #include "qcnn_internal.h"
 #include <utility>
@@ -112,6 +113,37 @@ __device__ __forceinline__ void requant12_int(const v4i &a, const v4i &b, const 
         : "=&v"(pa), "=&v"(pb), "=&v"(pc), "=&v"(ta), "=&v"(tb), "=&v"(tc)
         : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
           "s"(qab.mulk), "s"(qc.mulk));
+}
+
+// requant12_int for models whose C2 accumulators may leave the signed 24-bit range (the load-time proof of the
+// two-instruction form fails on the accumulator bounds only): s is first clamped to [-1, blu + q.bias], three
+// instructions per channel.  Every s above blu + q.bias requantises to 127 like blu itself and every negative s
+// to 0, and an accumulator beyond 2^24, where the reference's conversion to float rounds, is further than 2^23
+// from both thresholds whatever the rounding did (biases are at most 2^23 in magnitude on this path), so the
+// result equals the reference's float32 pipeline.  lim = blu + q.bias.
+__device__ __forceinline__ void requant12_wide(const v4i &a, const v4i &b, const v4i &c, const Requant &qab, const Requant &qc,
+                                               int limab, int limc, unsigned &pa, unsigned &pb, unsigned &pc)
+{
+    int ta, tb, tc;
+#define QCNN_WIDE_STEP(A, B, C, SEL, UNUSED)                                                                     \
+    "v_med3_i32 %3, " A ", -1, %20\n\t"                                                                          \
+    "v_med3_i32 %4, " B ", -1, %20\n\t"                                                                          \
+    "v_med3_i32 %5, " C ", -1, %21\n\t"                                                                          \
+    "v_mad_i32_i24 %3, %3, %18, 0 clamp\n\t"                                                                     \
+    "v_mad_i32_i24 %4, %4, %18, 0 clamp\n\t"                                                                     \
+    "v_mad_i32_i24 %5, %5, %19, 0 clamp\n\t"                                                                     \
+    "v_max_i32_sdwa %0, sext(%3), 0 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:BYTE_3 src1_sel:DWORD\n\t"    \
+    "v_max_i32_sdwa %1, sext(%4), 0 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:BYTE_3 src1_sel:DWORD\n\t"    \
+    "v_max_i32_sdwa %2, sext(%5), 0 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+    asm(QCNN_WIDE_STEP("%6", "%10", "%14", "BYTE_0", "UNUSED_PAD")
+        QCNN_WIDE_STEP("%7", "%11", "%15", "BYTE_1", "UNUSED_PRESERVE")
+        QCNN_WIDE_STEP("%8", "%12", "%16", "BYTE_2", "UNUSED_PRESERVE")
+        QCNN_WIDE_STEP("%9", "%13", "%17", "BYTE_3", "UNUSED_PRESERVE")
+        "s_nop 0"
+        : "=&v"(pa), "=&v"(pb), "=&v"(pc), "=&v"(ta), "=&v"(tb), "=&v"(tc)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+          "s"(qab.mulk), "s"(qc.mulk), "s"(limab), "s"(limc));
+#undef QCNN_WIDE_STEP
 }
 
 // requant12_int in four pieces, one per channel index I of the three dwords, so that a caller can place

@@ -96,6 +96,10 @@ struct C2Consts {
 #define C2_STAMP() do { } while (0)
 #endif
 
+// Instantiations of kernel A: integer epilogues (proved at load), the literal float32 pipeline, integer epilogues
+// with the C2 accumulators clamped first (fused_common.h, requant12_wide).
+enum { A_INT = 0, A_FLOAT = 1, A_WIDE = 2 };
+
 // Accumulators of the C2 stage of one wave: ROWS output rows x 16 columns x 48 channels.
 template <int ROWS>
 struct C2Acc {
@@ -105,7 +109,7 @@ struct C2Acc {
 // Requant of the accumulators and the store into conc1 (frame `concf`): rows R0 .. R0+ROWS-1, columns
 // cb .. cb+15 of the tile at (x0, y0).  Lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel
 // tile = 12 consecutive bytes at position 12g of the pixel in the internal channel order.
-template <bool EXACT, int ROWS>
+template <int MODE, int ROWS>
 __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb, int c, int g, const C2Consts &k, int8_t *concf,
                                          int x0, int y0, int H, int W)
 {
@@ -116,9 +120,13 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
     // the frame sits at rows / columns 2.. of the bordered conc1 image
     const size_t row_bytes = (size_t)conc_wp(W) * 48;  // row y sits y * row_bytes further
     int8_t *out = concf + (size_t)(gy0 + 2) * row_bytes + (size_t)(gx + 2) * 48 + 12 * g;
+    constexpr bool EXACT = MODE == A_FLOAT;
     auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
-        if constexpr (!EXACT) {
+        if constexpr (MODE == A_INT) {
             requant12_int(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, d0, d1, d2);
+        } else if constexpr (MODE == A_WIDE) {
+            requant12_wide(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, k.q21.blu + k.q21.bias, k.q22.blu + k.q22.bias, d0,
+                           d1, d2);
         } else {
             d0 = quant4<EXACT>(acc.a21[0][y][0], acc.a21[0][y][1], acc.a21[0][y][2], acc.a21[0][y][3], k.bf[0], k.bf[1], k.bf[2],
                                k.bf[3], k.q21);
@@ -281,11 +289,12 @@ __device__ __forceinline__ void mid_barrier()
 #endif
 }
 
-template <bool EXACT>
+template <int PATH>
 __global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_waves_per_eu(A_WAVES / 4, A_WAVES / 4)))
 void k_c1c2(const FusedArgs a)
 {
     using namespace ka;
+    constexpr bool EXACT = PATH == A_FLOAT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     // [2][C1R][C1C][64] int8 C1 output tiles (chunk-swizzled), one private Y tile per producer,
     // then all 43 C2 A fragments (loaded once per workgroup, read by every consumer tile)
@@ -469,7 +478,7 @@ void k_c1c2(const FusedArgs a)
                     C2Acc<8 - C2_CONS_ROWS> acc;
                     c2_mfma<EXACT, 8 - C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
                                                      [] {});
-                    c2_store<EXACT, 8 - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
+                    c2_store<PATH, 8 - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
                                                       a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
                 }
             }
@@ -621,7 +630,7 @@ void k_c1c2(const FusedArgs a)
             bool have = false;
             auto store_held = [&] {
                 if (have)
-                    c2_store<EXACT, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
+                    c2_store<PATH, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
                                              held.ty * TH, H, W);
             };
             auto store_then_release = [&] {
@@ -645,7 +654,7 @@ void k_c1c2(const FusedArgs a)
                         set_prio<C2_PRIO_N_MFMA>();
                         c2_mfma<EXACT, C2_ROWS>(acc, buf, R0c, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
                         set_prio<C2_PRIO_N_VALU>();
-                        c2_store<EXACT, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
+                        c2_store<PATH, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
                                                  pos.ty * TH, H, W);
                     }
 #endif
@@ -674,14 +683,16 @@ void k_c1c2(const FusedArgs a)
     }
 }
 
-hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s)
+// mode: 0 integer epilogues, 1 float pipeline, 2 integer epilogues with clamped C2 accumulators
+hipError_t launch_fused_c1c2(const FusedArgs &a, int mode, hipStream_t s)
 {
     const int ntiles = ((a.W + ka::TW - 1) / ka::TW) * ((a.H + ka::TH - 1) / ka::TH) * a.nframes;
     if (ntiles < 1) return hipSuccess;
     const int ncu = a.ncu > 0 ? a.ncu : 256;
     dim3 grid(ntiles < ncu ? ntiles : ncu);
-    if (exact) hipLaunchKernelGGL(k_c1c2<true>, grid, dim3(A_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_c1c2<false>, grid, dim3(A_THREADS), 0, s, a);
+    if (mode == A_FLOAT) hipLaunchKernelGGL(k_c1c2<A_FLOAT>, grid, dim3(A_THREADS), 0, s, a);
+    else if (mode == A_WIDE) hipLaunchKernelGGL(k_c1c2<A_WIDE>, grid, dim3(A_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_c1c2<A_INT>, grid, dim3(A_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -200,7 +200,7 @@ hipError_t launch_sse_clip(const void *in, const void *out, const void *ori, siz
                            unsigned long long *sum_before, unsigned long long *sum_after, hipStream_t s);
 hipError_t launch_conc_to_ref(const void *conc_internal, void *conc_ref, int H, int W, hipStream_t s);
 hipError_t launch_conc_zero_border(void *conc_internal, int nframes, int H, int W, hipStream_t s);
-hipError_t launch_fused_c1c2(const FusedArgs &a, bool exact, hipStream_t s);
+hipError_t launch_fused_c1c2(const FusedArgs &a, int mode, hipStream_t s);  // 0 integer, 1 float pipeline, 2 clamped integer
 hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s);         // tiled form (kernels_fused_b.hip)
 hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t s);  // streaming form (kernels_fused_s.hip)
 

@@ -137,12 +137,21 @@ class qvrcnn:
         capi.check(self._lib.qcnn_layer_params(self._h, layer, C.byref(b), C.byref(m), C.byref(s)))
         return b.value, m.value, s.value
 
-    def set_exact(self, on: bool) -> None:
+    def set_exact(self, on) -> None:
+        """From the next load on: 1 / True forces the float-pipeline kernels, 2 the clamped integer form of kernel A,
+        0 / False returns to what the load-time proof chooses."""
         capi.check(self._lib.qcnn_set_exact(self._h, int(on)))
 
     @property
+    def arith_paths(self):
+        """(kernel A, kernel B): 0 integer epilogues, 1 float pipeline, 2 integer epilogues on clamped C2 accumulators."""
+        v = capi.check(self._lib.qcnn_is_exact(self._h))
+        return v & 15, v >> 4
+
+    @property
     def is_exact(self) -> bool:
-        return bool(capi.check(self._lib.qcnn_is_exact(self._h)))
+        """True when a fused kernel replays the float32 pipeline literally for the loaded model."""
+        return 1 in self.arith_paths
 
     def bind_io(self, dev_y: int, dev_rec: int) -> None:
         capi.check(self._lib.qcnn_bind_io(self._h, C.c_void_p(dev_y), C.c_void_p(dev_rec)))

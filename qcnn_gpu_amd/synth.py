@@ -140,6 +140,9 @@ def adversarial_model(kind: str) -> StaticModel:
     'wide'     : full-magnitude weights on as many taps as keep sum|w| * 127 + |b| just below 2^23, with
                  the usual clip thresholds: accumulators run from far below zero to hundreds of times
                  the threshold, which is what the integer requantiser's saturating multiply must survive.
+    'heavy'    : C1 and C2 at full magnitude on every tap with the usual requantisers and small biases: the C2_2
+                 accumulators pass 2^24 on bright input (where the reference's float conversion rounds) and
+                 -2^23 on the mixed-sign channels; C3 and C4 as trained.  Kernel A takes its clamped integer form.
     'balanced' : dense weights of both signs in equal numbers, as large as keep the sum of the positive and
                  the sum of the negative weights of a channel, times 127, below 2^23 each while sum|w| * 127
                  passes 2^23 in C2_1 and C2_2: activations are never negative, so the accumulators stay
@@ -155,6 +158,21 @@ def adversarial_model(kind: str) -> StaticModel:
             lp.b = np.full(lp.b.shape, (1 << 24) + 3 if l == 2 else 12345, np.int32)
             if l < 5:
                 lp.blu, lp.mul, lp.shift = (1 << 25), 1, 18
+        return m
+    if kind == "heavy":
+        for l in (0, 1, 2):
+            lp = m.layers[l]
+            co = lp.w.shape[0]
+            per = lp.w[0].size
+            w = np.empty((co, per), np.int64)
+            for k in range(co):
+                i = np.arange(per)
+                if k % 2 == 0:
+                    w[k] = 127                                       # all-positive channel
+                else:
+                    w[k] = np.where((i * 7 + k) % 10 < 3, 127, -128)  # 70 % negative
+            lp.w = w.astype(np.int8).reshape(lp.w.shape)
+            lp.b = ((np.arange(co) % 9 - 4) * 3000 + 17).astype(np.int32)
         return m
     if kind == "wide":
         for l, lp in enumerate(m.layers):

@@ -100,13 +100,17 @@ def test_fused_float_pipeline_variant(qp):
         net.load_static_para(mb)
         assert net.is_exact
         _check_fused(net, y, rec_o, taps_o["conc1"])
+        net.set_exact(2)          # kernel A with its C2 accumulators clamped first
+        net.load_static_para(mb)
+        assert net.arith_paths == (2, 0)
+        _check_fused(net, y, rec_o, taps_o["conc1"])
         net.set_exact(False)
         net.load_static_para(mb)
-        assert not net.is_exact
+        assert not net.is_exact and net.arith_paths == (0, 0)
         _check_fused(net, y, rec_o, taps_o["conc1"])
 
 
-@pytest.mark.parametrize("kind", ["maxmag", "identity", "wide", "balanced"])
+@pytest.mark.parametrize("kind", ["maxmag", "identity", "wide", "balanced", "heavy"])
 def test_adversarial_models(kind):
     m = synth.adversarial_model(kind)
     mb = m.to_nchw_vect_c_bytes()
@@ -123,7 +127,11 @@ def test_adversarial_models(kind):
         if kind == "maxmag":
             assert net.is_exact               # accumulators can pass 2^24: float pipeline is selected
         if kind in ("wide", "balanced"):
-            assert not net.is_exact           # inside the 24-bit operand range: integer requantiser
+            assert net.arith_paths == (0, 0)  # inside the 24-bit operand range: integer requantiser
+        if kind == "heavy":
+            # C2 accumulator bounds beyond 2^24, everything else in range: clamped integers in kernel A, plain in B
+            pos = [np.maximum(lp.w.astype(np.int64), 0).reshape(lp.w.shape[0], -1).sum(1).max() * 127 for lp in m.layers]
+            assert pos[2] > 1 << 24 and net.arith_paths == (2, 0)
         for y in frames:
             rec_o, taps_o = _check_layered(net, mb, y)
             _check_fused(net, y, rec_o, taps_o["conc1"])
@@ -333,7 +341,7 @@ def test_random_shapes_and_batches_against_oracle():
         capi.check(lib.qcnn_dev_alloc(C.byref(d_out), nf * h * w))
         capi.check(lib.qcnn_dev_h2d(d_in, np.ascontiguousarray(frames).ctypes.data, nf * h * w))
         with qvrcnn(0, 1, 1, h, w) as net:
-            for exact in ((False, True) if k % 3 == 0 else (False,)):
+            for exact in ((False, True) if k % 3 == 0 else (False, 2) if k % 3 == 1 else (False,)):
                 net.set_exact(exact)
                 net.load_static_para(mb)
                 capi.check(lib.qcnn_dev_memset(d_out, 0x5A, nf * h * w))
