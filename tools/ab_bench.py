@@ -5,7 +5,8 @@
 
 Each named build is loaded in a child process (one library per process) and reports the mean launch
 time of k_c1c2 / k_c3c4 over 20 steps, so that two builds can be compared on the same device in the
-same session (device-to-device differences are larger than most kernel changes)."""
+same session (device-to-device differences are larger than most kernel changes).  Short bursts ride the boost
+clock: AB_FRAMES=512 AB_PREWARM=2 gives the sustained figures of bench.py."""
 import os
 import subprocess
 import sys
@@ -20,6 +21,9 @@ from qcnn_gpu_amd import capi, synth
 capi.LIB_PATH = os.path.join(%(root)r, "qcnn_gpu_amd", %(lib)r, "libqcnn.so")
 from qcnn_gpu_amd.qvrcnn import qvrcnn
 h, w, qp, B = (2160, 3840, 32, 5) if os.environ.get("AB_4K") else (1080, 1920, 37, 16)
+B = int(os.environ.get("AB_FRAMES", B))              # resident frames per step
+steps = int(os.environ.get("AB_STEPS", 20))
+prewarm = float(os.environ.get("AB_PREWARM", 0))     # seconds of untimed steps first (sustained clocks)
 lib = capi.load()
 net = qvrcnn(0, 1, 1, h, w)
 if os.environ.get("AB_EXACT"): net.set_exact(True)
@@ -30,14 +34,18 @@ capi.check(lib.qcnn_dev_alloc(C.byref(d_in), B * h * w)); capi.check(lib.qcnn_de
 for i in range(B):
     f = np.ascontiguousarray(anc[i %% 4]); capi.check(lib.qcnn_dev_h2d(C.c_void_p(d_in.value + i * h * w), f.ctypes.data, h * w))
 for _ in range(5): net.forward_blu_batch(d_in.value, d_out.value, B, h * w)
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < prewarm:
+    net.forward_blu_batch(d_in.value, d_out.value, B, h * w); capi.check(lib.qcnn_dev_sync())
 capi.check(lib.qcnn_dev_sync()); net.set_timing(True); net.kernel_times_us(reset=True)
 t0 = time.perf_counter()
-for _ in range(20): net.forward_blu_batch(d_in.value, d_out.value, B, h * w)
+for _ in range(steps): net.forward_blu_batch(d_in.value, d_out.value, B, h * w)
 capi.check(lib.qcnn_dev_sync()); dt = time.perf_counter() - t0
 ka, kb, n = net.kernel_times_us()
+ka, kb = ka * n / steps, kb * n / steps  # per step (a step of more than one launch group)
 import zlib
 out = np.empty(B * h * w, np.uint8); capi.check(lib.qcnn_dev_d2h(out.ctypes.data, d_out, B * h * w))
-print("%%-10s k_c1c2 %%7.1f us/frame  k_c3c4 %%7.1f us/frame  total %%8.1f Mpx/s  crc32(out) %%08x" %% (%(lib)r, ka / B, kb / B, 20 * B * h * w / dt / 1e6, zlib.crc32(out.tobytes())))
+print("%%-10s k_c1c2 %%7.1f us/frame  k_c3c4 %%7.1f us/frame  total %%8.1f Mpx/s  crc32(out) %%08x" %% (%(lib)r, ka / B, kb / B, steps * B * h * w / dt / 1e6, zlib.crc32(out.tobytes())))
 """
 
 if len(sys.argv) == 3 and sys.argv[1] == "--inline":  # this process itself (for use under rocprofv3)
