@@ -17,8 +17,13 @@
 //   * the three kernel rows are summed in the lane over three consecutive conc2 rows (rolling partial sums),
 //     the three kernel columns with two cross-lane gathers (ds_bpermute: pixel + s of lane row s), then
 //     applyRes_y and a byte store for the 14 output pixels of the row.
-// The frame is cut into strips x bands (x frames): thousands of independent waves, twelve per CU, whose
-// MFMA and vector phases interleave as the hardware schedules them.  Zero padding: conc1 comes with a
+// The frame is cut into strips x bands (x frames): thousands of waves, twelve per CU, whose MFMA and vector
+// phases interleave as the hardware schedules them.
+// Every wave is on its own (no barrier anywhere).  An experiment build (ks::SHARED, measured slower, see
+// qcnn_internal.h) lets the waves of a workgroup walk neighbouring strips of one band and share ONE ring of conc1
+// rows in three groups of ks::R rows: each wave fetches its share of every row, so the four columns two
+// neighbouring strips have in common come from HBM once, and one workgroup barrier per ks::R rows keeps a wave
+// from reading a row its neighbours have not fetched yet or fetching into a slot they still read.  Zero padding: conc1 comes with a
 // border of zeros in HBM (qcnn_internal.h, conc_bytes), conc2 pixels outside the frame are zeroed in
 // registers.
 #define STAMP_ROW (wv + 12)  // diagnostic builds: rows 12..15 of the stamp buffer (kernel A owns 0..11)
@@ -71,7 +76,7 @@ template <bool EXACT>
 __global__ __launch_bounds__(ks::WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_units)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroups are dealt to the 8 XCDs round robin; XCD x takes the x-th eighth of the units, so that strips that
@@ -79,17 +84,31 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // (the grid is a multiple of 8 workgroups, so the map is one to one)
     const int per_xcd = gridDim.x >> 3;
     const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    int unit = wg * WAVES + wv;
-    if (unit >= total_units) return;  // the waves of a workgroup never meet again: no barrier anywhere
-    const int strip = unit % nstrips;
-    unit /= nstrips;
-    const int seg = unit % nseg, f = unit / nseg;
+    int strip, seg, f, xw;  // xw: first column of the ring rows in the bordered image
+    if constexpr (SHARED) {
+        // a workgroup = WAVES neighbouring strips of one band of one frame; total_units counts workgroups.  A wave
+        // whose strip lies past the last one still fetches its share of the rows and meets the barriers; it owns
+        // no pixel (every test on x0 below fails for it).
+        if (wg >= total_units) return;
+        const int nsw = (nstrips + WAVES - 1) / WAVES;
+        const int sg = wg % nsw, rest = wg / nsw;
+        seg = rest % nseg, f = rest / nseg;
+        strip = sg * WAVES + wv;
+        xw = sg * WAVES * SW;
+    } else {
+        int unit = wg * WAVES + wv;
+        if (unit >= total_units) return;  // the waves of a workgroup never meet again: no barrier anywhere
+        strip = unit % nstrips;
+        unit /= nstrips;
+        seg = unit % nseg, f = unit / nseg;
+        xw = strip * SW;
+    }
     const int H = a.H, W = a.W;
     const int x0 = strip * SW, ya = seg * seg_rows;
     const int yb = ya + seg_rows < H ? ya + seg_rows : H;  // output rows ya .. yb-1
-    if (ya >= yb) return;
-    unsigned char *ring = smem + wv * WAVE_LDS;   // conc1 rows: two groups of R
-    unsigned char *yring = ring + RING_BYTES;     // Y rows: 2 R x 16 dwords
+    if (ya >= yb) return;  // (the same for every wave of a workgroup)
+    unsigned char *ring = SHARED ? smem : smem + wv * RING_BYTES;                             // conc1 rows: GROUPS groups of R
+    unsigned char *yring = smem + (SHARED ? 1 : WAVES) * RING_BYTES + wv * YRING_BYTES;        // Y rows: 2 R x 16 dwords
     const int g = lane >> 4;
     const int pix = kb_pixel_of_lane(lane & 15);  // region pixel of this lane: image column x0 - 1 + pix
     const int gc = kb_chunk_of_kgroup(g);
@@ -155,13 +174,15 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     constexpr int OOB = 0x7f000000;
     const int lane16 = lane * 16;
     const int y_voff = (lane < SW && x0 + lane < W) ? lane : OOB;
-    const unsigned long long row_lanes = (1ull << (ROW_BYTES / 16)) - 1;
+    const unsigned long long row_lanes = (1ull << ROW_PIECES) - 1;
 
     const unsigned ring_s = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);  // LDS byte addresses
-    const unsigned yring_s = ring_s + RING_BYTES;
-    // requests conc1 row `crow` of the bordered image and the Y pixels of output row `yrow` into ring slot
-    // (grp, j): row j of group grp
-    auto request = [&](int grp, int j, int crow, int yrow, bool clamp) {
+    const unsigned yring_s = __builtin_amdgcn_readfirstlane((unsigned)(size_t)yring);
+    // this wave's share of a ring row: all of it, or pieces wv * ROW_PIECES .. of the workgroup's shared row
+    const int share = SHARED ? wv * ROW_PIECES * 16 : 0;
+    // requests conc1 row `crow` of the bordered image into row j of ring group `grp` and the Y pixels of output row
+    // `yrow` into row j of Y group `ygrp`
+    auto request = [&](int grp, int ygrp, int j, int crow, int yrow, bool clamp) {
         if (clamp) {  // rows past the border / outside the frame are never used: any row inside will do
             crow = crow <= H + 3 ? crow : H + 3;
             yrow = yrow < 0 ? 0 : yrow >= H ? H - 1 : yrow;
@@ -169,15 +190,15 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
 #ifdef QCNN_ABL_L2LOADS  // diagnostic builds only: every load hits a few rows that stay in L2
         crow &= 7;
 #endif
-        const unsigned lds_c = ring_s + grp * GROUP_BYTES + j * ROW_BYTES, lds_y = yring_s + (grp * R + j) * 64;
-        const int off_c = crow * row_bytes + x0 * 48, off_y = yrow * W + x0;
+        const unsigned lds_c = ring_s + grp * GROUP_BYTES + j * ROW_BYTES + share, lds_y = yring_s + (ygrp * R + j) * YSLOT;
+        const int off_c = crow * row_bytes + xw * 48 + share, off_y = yrow * W + x0;
         unsigned long long saved;
         asm volatile("s_mov_b64 %0, exec\n\t"
                      "s_mov_b32 m0, %1\n\t"
                      "s_mov_b64 exec, %2\n\t"
                      "buffer_load_dwordx4 %3, %4, %5 offen" QCNN_CONC_LOAD_AUX " lds\n\t"
                      "s_mov_b32 m0, %6\n\t"
-                     "s_mov_b64 exec, 0xffff\n\t"
+                     "s_mov_b64 exec, 0x3fff\n\t"
                      "buffer_load_ubyte %7, %8, %9 offen lds\n\t"
                      "s_mov_b64 exec, %0"
                      : "=&s"(saved)
@@ -186,9 +207,9 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
                      : "memory");
     };
     // the lane's read addresses: B fragments of a conc1 row (+ group * GROUP_BYTES + row * 864 + s * 48), the Y
-    // pixel of its column (+ slot * 64)
-    const unsigned char *rd = ring + pix * 48 + gc * 16;
-    const unsigned char *rdy = yring + pix * 4;
+    // pixel of its column (+ slot * YSLOT)
+    const unsigned char *rd = ring + ((SHARED ? wv * SW : 0) + pix) * 48 + gc * 16;
+    const unsigned char *rdy = yring + (pix < SW ? pix : 0) * 4;  // (lanes past the strip read a pixel they never use)
 
     // output: lane (pixel o, lane row 0) owns output column x0 + o, o < 14
     const bool outlane = g == 0 && pix < SW && x0 + pix < W;
@@ -213,11 +234,12 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     const int T = (yb - ya + 5 + R - 1) / R;
     // the ring's first 2R rows, all landed before the first row starts
 #pragma unroll
-    for (int i = 0; i < 2 * R; ++i) request(i / R, i % R, ya + i, ya - 5 + i, true);
+    for (int i = 0; i < 2 * R; ++i) request(i / R, i / R, i % R, ya + i, ya - 5 + i, true);
     // (as a builtin: the compiler then knows that its own loads above, the weights and biases, have landed too,
     // and places no wait for them inside the loops)
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     asm volatile("" ::: "memory");
+    if constexpr (SHARED) asm volatile("s_barrier" ::: "memory");  // ... and every other wave's share of them
 
     v4i acc[3] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
     v4i a32[2][2] = {{v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}, {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}};
@@ -228,6 +250,16 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
 #pragma unroll
     for (int s = 0; s < 3; ++s) Bq[0][s] = *reinterpret_cast<const v4i *>(rd + s * 48);
 
+    // ring groups of step t: read (g3), next (g3n), refilled by this step's requests (g3r)
+    int g3 = 0, g3n = 1, g3r = SHARED ? 2 : 0;
+    auto next_groups = [&] {
+        if constexpr (SHARED) {
+            const int old = g3;
+            g3 = g3n, g3n = g3r, g3r = old;
+        } else {
+            g3 ^= 1, g3n ^= 1, g3r = g3;
+        }
+    };
     STAMP_INIT();
     // One conc1 row.  CHECK = false: a step whose six conc2 rows lie inside the frame and whose six output rows lie
     // inside the band, in a strip with no column outside the frame; every test below is then known to hold.
@@ -235,7 +267,9 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         constexpr int j = decltype(jc)::value;
         constexpr bool CHECK = decltype(checkc)::value;
         const int m0 = R * t;
-        const unsigned char *rdc = rd + (t & 1) * GROUP_BYTES, *rdo = rd + ((t + 1) & 1) * GROUP_BYTES;
+        // ring group of this step, of the next one, and the one this step refills (per-wave rings: two groups, the
+        // slot a row has just emptied; shared ring: three, the group all waves left at the last barrier)
+        const unsigned char *rdc = rd + g3 * GROUP_BYTES, *rdo = rd + g3n * GROUP_BYTES;
         static_assert(R % 2 == 0 && R % 3 == 0, "the fragment and accumulator slots repeat with the step");
         v4i(&B)[3] = Bq[j & 1];
         v4i(&Bn)[3] = Bq[(j + 1) & 1];
@@ -243,7 +277,20 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         // steps request nothing, so only their 10 stores are certain to be younger)
         if (CHECK && t >= T - 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
-        const int yv = *reinterpret_cast<const int *>(rdy + ((t & 1) * R + j) * 64);
+        if constexpr (SHARED && j == R - 1) {
+            // Once per step, ahead of the first read of the next group: this wave's share of that group has landed
+            // (its last row was requested R rows ago; behind that load sit its Y load and three instructions of each
+            // of the R - 1 rows since: 16; the last steps issue fewer), and after the barrier so has everybody
+            // else's.  The barrier also tells that every wave has read the last row of the previous group (its
+            // fragments are in registers: lgkmcnt(0)), which the next step refills.
+#ifdef QCNN_ABL_NOBAR  // diagnostic builds only (garbage results): what the barrier costs
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#else
+            if (CHECK && t >= T - 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+        }
+        const int yv = *reinterpret_cast<const int *>(rdy + ((t & 1) * R + j) * YSLOT);
         // the fragments of the next row (the first row of the other group after the last row of this one)
         if constexpr (j + 1 < R) {
 #pragma unroll
@@ -333,7 +380,7 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         }
         // (rows past the last one the band walks are not requested: when the wave ends and its LDS is handed to
         // the next workgroup, no load may still be on its way into it)
-        if (!CHECK || t <= T - 3) request(t & 1, j, ya + m0 + j + 2 * R, y3 + 2 * R, CHECK);
+        if (!CHECK || t <= T - 3) request(g3r, t & 1, j, ya + m0 + j + 2 * R, y3 + 2 * R, CHECK);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!EXACT) {
             REQ_PIECE(3, true);
@@ -373,9 +420,18 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         if (t_lo > t_hi) t_lo = t_hi;
     }
     int t = 0;
-    for (; t < t_lo; ++t) static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
-    for (; t < t_hi; ++t) static_for<R>([&](auto jc) { row(jc, std::false_type{}, t); });
-    for (; t < T; ++t) static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
+    for (; t < t_lo; ++t) {
+        static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
+        next_groups();
+    }
+    for (; t < t_hi; ++t) {
+        static_for<R>([&](auto jc) { row(jc, std::false_type{}, t); });
+        next_groups();
+    }
+    for (; t < T; ++t) {
+        static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
+        next_groups();
+    }
 }
 
 hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t s)
@@ -402,9 +458,12 @@ hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t 
     }
     if (seg_rows > a.H) seg_rows = a.H;
     const int nseg = (a.H + seg_rows - 1) / seg_rows;
-    const long long units = (long long)a.nframes * nstrips * nseg;
+    // units the kernel counts: workgroups of WAVES neighbouring strips (shared ring) or single strips
+    const long long per_band = ks::SHARED ? (nstrips + ks::WAVES - 1) / ks::WAVES : nstrips;
+    const long long units = (long long)a.nframes * per_band * nseg;
     if (units > (1ll << 30)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(((units + ks::WAVES - 1) / ks::WAVES + 7) / 8 * 8));  // a multiple of 8: see the unit map
+    const long long wgs = ks::SHARED ? units : (units + ks::WAVES - 1) / ks::WAVES;
+    const dim3 grid((unsigned)((wgs + 7) / 8 * 8));  // a multiple of 8: see the unit map
     if (exact) hipLaunchKernelGGL(k_c3c4s<true>, grid, dim3(ks::WAVES * 64), 0, s, a, nstrips, nseg, seg_rows, (int)units);
     else hipLaunchKernelGGL(k_c3c4s<false>, grid, dim3(ks::WAVES * 64), 0, s, a, nstrips, nseg, seg_rows, (int)units);
     return hipGetLastError();

@@ -55,18 +55,35 @@ static_assert(LDS_BYTES <= 160 * 1024, "kernel B exceeds the 160 KiB of LDS of o
 }  // namespace kb
 
 // Kernel B, streaming form: every wave walks a strip of 14 output columns down a band of rows, see
-// kernels_fused_s.hip.
+// kernels_fused_s.hip.  QCNN_S_SHARED = 0 (shipped): four independent waves per workgroup with a ring of conc1
+// rows each (18 columns per strip).  1 (experiment, measured slower): the QCNN_S_WAVES waves of a workgroup walk
+// neighbouring strips and share one ring (each wave fetches its share of a row, the four columns two
+// neighbouring strips have in common are fetched once; one barrier per R rows): 14 % fewer bytes from HBM, yet
+// 29.1 against 26.8 us per 1080p frame with 4 or 12 waves per workgroup (28.4 with the barriers taken out), 35.5
+// with 6 (two waves more on two of the four SIMDs).
+#ifndef QCNN_S_SHARED
+#define QCNN_S_SHARED 0
+#endif
 namespace ks {
+constexpr bool SHARED = QCNN_S_SHARED != 0;
 constexpr int SW = 14;                        // output columns of a strip (C3 region 16, conc1 18 columns)
 constexpr int CW = SW + 4;                    // conc1 columns a strip reads (halo 2)
 constexpr int R = 6;                          // conc1 rows per step of the unrolled row loop
-constexpr int ROW_BYTES = CW * 48;            // one conc1 row of a strip: 864 contiguous bytes of the HBM image
-constexpr int GROUP_BYTES = R * ROW_BYTES + 64;   // R rows (+ slack: a fragment read runs 16 bytes past its pixel)
-constexpr int RING_BYTES = 2 * GROUP_BYTES;       // conc1 ring of one wave: 2 R row slots
-constexpr int YRING_BYTES = 2 * R * 64;           // Y ring of one wave: 2 R slots of 16 dwords (one pixel each)
-constexpr int WAVE_LDS = RING_BYTES + YRING_BYTES;
-constexpr int WAVES = 4;                      // waves per workgroup (they never synchronise)
-static_assert(3 * WAVES * WAVE_LDS <= 160 * 1024, "three workgroups per CU");
+#ifndef QCNN_S_WAVES
+#define QCNN_S_WAVES 4
+#endif
+constexpr int WAVES = SHARED ? QCNN_S_WAVES : 4;  // waves per workgroup
+constexpr int RING_COLS = SHARED ? WAVES * SW + 4 : CW;   // conc1 columns of one ring row
+constexpr int ROW_BYTES = RING_COLS * 48;     // one ring row: contiguous bytes of the HBM image (864 / 4224)
+constexpr int ROW_PIECES = ROW_BYTES / 16 / (SHARED ? WAVES : 1);  // 16-byte pieces of a row one wave fetches (54 / 44)
+constexpr int GROUPS = SHARED ? 3 : 2;        // groups of R row slots in a ring
+constexpr int GROUP_BYTES = R * ROW_BYTES;        // R rows
+constexpr int RING_BYTES = GROUPS * GROUP_BYTES + 64;  // one conc1 ring (+ slack: a fragment read runs 16 bytes past its pixel)
+constexpr int YSLOT = SW * 4;                     // Y pixels of one output row of a strip, a dword each
+constexpr int YRING_BYTES = 2 * R * YSLOT;        // Y ring of one wave: 2 R slots
+constexpr int WG_LDS = (SHARED ? RING_BYTES : WAVES * RING_BYTES) + WAVES * YRING_BYTES;
+static_assert(ROW_BYTES % (16 * (SHARED ? WAVES : 1)) == 0 && ROW_PIECES <= 64, "a wave fetches its share of a row with one instruction");
+static_assert((12 / WAVES) * WG_LDS <= 160 * 1024, "twelve waves per CU");
 }  // namespace ks
 
 // The conc1 hand-off image in HBM: int8 [H + 4][W + 4][48] per frame, the frame at rows 2..H+1, columns

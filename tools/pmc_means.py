@@ -5,7 +5,7 @@ import collections, csv, glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 means = {}
-for d in sorted(glob.glob(P + "/pmc_*")):
+for d in (sys.argv[1:] or sorted(glob.glob(P + "/pmc_*"))):  # or: the pass directories named on the command line
     fs = sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)
     if not fs:
         continue
