@@ -177,6 +177,26 @@ def test_full_hd_frame_bit_exact():
         net.synchronize()
         assert np.array_equal(net.download(), rec_o)
         assert np.array_equal(net.tap(capi.TAP_CONC2), taps_o["conc2"])
+        # the clamped integer form of kernel A and the float pipeline on the same frame
+        for mode in (2, 1):
+            net.set_exact(mode)
+            net.load_static_para(mb)
+            assert net.arith_paths == ((2, 0) if mode == 2 else (1, 1))
+            _check_fused(net, anc[0], rec_o, taps_o["conc1"])
+
+
+def test_full_hd_heavy_model_bit_exact():
+    """A 1920x1080 frame through the model whose C2 accumulator bounds pass 2^24 (clamped integer form of kernel A
+    chosen by the load-time proof), white and textured input, memcmp-equal with the oracle."""
+    h, w = 1080, 1920
+    mb = synth.adversarial_model("heavy").to_nchw_vect_c_bytes()
+    y = np.array(_frame(h, w, 37), np.uint8, order="C")
+    y[: h // 3] = 255          # a white band: every C1 channel with positive weights saturates, C2_2 passes 2^24
+    rec_o, taps_o = c_oracle.forward_blu(mb, y, True)
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        assert net.arith_paths == (2, 0)
+        _check_fused(net, y, rec_o, taps_o["conc1"])
 
 
 def test_4k_frame_qp32_bit_exact():
