@@ -293,7 +293,9 @@ def main():
                          "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic,
                          "note": "int8 ops (2 per MAC); algorithmic 91 264 ops/pixel for this kernel x %d pixels per launch "
                                  "(%d frames); avg launch %.1f us (k_c3c4: %.1f us) over %d launches, HIP events on the engine "
-                                 "stream in an untimed pass after the timed region"
+                                 "stream in an untimed pass after the timed region; peak = nominal dense int8 rate at 2.4 GHz (a loop of "
+                                 "nothing but int8 MFMAs on random operands sustains 3.9-4.1 POP/s at 1.9-2.0 GHz on this device class: "
+                                 "profiles/r02_issue_ubench.txt)"
                                  % (hw * fpl, fpl, ka_us, kb_us, passes),
                          "whole_pass_frac": round((2.0 * MACS_PER_PIXEL * hw * fpl / ((ka_us + kb_us) * 1e-6) / 1e12) / PEAK_INT8_TOPS, 4)
                                             if ka_us + kb_us > 0 else None,
