@@ -223,8 +223,9 @@ __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *b
 // SIMD would compute the rest after its C1 work.  Measured: with 7 the step does not get shorter (the
 // MFMA pipe and the vector issue port are shared by the two waves either way, and the producer's
 // one-row share reuses no fragment), so the consumer keeps all 8.
+constexpr int C2_BLOCK_ROWS = ka::TH / 2;  // rows of the 16-column block the consumers of one SIMD compute
 #ifndef C2_CONS_ROWS_N
-#define C2_CONS_ROWS_N 8
+#define C2_CONS_ROWS_N C2_BLOCK_ROWS
 #endif
 constexpr int C2_CONS_ROWS = C2_CONS_ROWS_N;
 // When the producer runs its share: 1 = at the start of the step, next to the consumer's requant + store phase;
@@ -266,7 +267,8 @@ __device__ __forceinline__ void set_prio()
 {
     if constexpr (P >= 0) asm volatile("s_setprio %0" ::"n"(P));
 }
-static_assert(C2_CONSUMERS == 1 || (C2_CONSUMERS == 2 && C2_CONS_ROWS == 8), "two consumers split all 8 rows");
+static_assert(C2_CONSUMERS == 1 || (C2_CONSUMERS == 2 && C2_CONS_ROWS == C2_BLOCK_ROWS && C2_BLOCK_ROWS % 2 == 0),
+              "two consumers split all rows of the block");
 constexpr int C2_ROWS = C2_CONS_ROWS / C2_CONSUMERS;      // rows of one consumer wave
 constexpr int A_WAVES = 4 + 4 * C2_CONSUMERS, A_THREADS = 64 * A_WAVES;
 
@@ -341,7 +343,7 @@ void k_c1c2(const FusedArgs a)
     // C2 constants of this lane, used by the consumer and by the producer's share of the C2 rows
     const int c = lane & 15, g = lane >> 4;
     const int blk = wv & 3;  // the 8 x 16 output block of this SIMD's consumer / producer pair
-    const int cb = (blk & 1) * 16, R0 = (blk >> 1) * 8;
+    const int cb = (blk & 1) * 16, R0 = (blk >> 1) * C2_BLOCK_ROWS;
     const v4i *w22 = reinterpret_cast<const v4i *>(sW) + lane;
     const v4i *w21 = reinterpret_cast<const v4i *>(sW + (PackedOffsets::C2W21 - PackedOffsets::C2W22)) + lane;
     C2Consts kc;
@@ -424,7 +426,7 @@ void k_c1c2(const FusedArgs a)
             group_consts(1, k, rdw[k], wrw[k], unused, true);
         }
         const bool last_valid[2] = {(NKC - 1) * 32 + (lane & 31) < PROD_ROWS * C1C, (NKW - 1) * 32 + (lane & 31) < WARM_ROWS * C1C};
-        constexpr int YLOADS = (9 * YWC + 63) / 64;  // bytes of the private Y tile per lane
+        constexpr int YLOADS = (YROWS * YWC + 63) / 64;  // bytes of the private Y tile per lane
         // byte `it` of this lane (frame-edge tiles only): row and column relative to the tile's first halo pixel, LDS
         // offset in copy 0 (copy c sits c * (YCOPY - 1) further; -1: no byte)
         auto ybyte = [&](int it, int &row, int &col) {
@@ -432,7 +434,7 @@ void k_c1c2(const FusedArgs a)
             asm volatile("" : "+v"(l));  // (as above)
             const int idx = it * 64 + l;
             row = idx / YWC, col = idx - row * YWC;
-            return idx < 9 * YWC ? row * YWS + col + 4 : -1;
+            return idx < YROWS * YWC ? row * YWS + col + 4 : -1;
         };
         // The same tile in one load, for tiles whose halo (and 3 bytes beyond it) lies inside the frame:
         // lane (row, j), j = 0..4, loads the 12 bytes 8j .. 8j+11 of tile row `row` and derives from them
@@ -442,7 +444,8 @@ void k_c1c2(const FusedArgs a)
         // only meet zero weights).
         static_assert(YWC == 40 && YCOPY % 4 == 0, "five 8-byte pieces per tile row");
         const int yrow4 = lane / 5, yj4 = lane - yrow4 * 5;
-        const bool ylane4 = lane < 45;
+        const bool ylane4 = lane < 5 * YROWS;
+        static_assert(5 * YROWS <= 64, "one lane per 8-byte piece of the private Y tile");
         const int goff4 = ylane4 ? yrow4 * W + 8 * yj4 : 0;
         const int lwr4 = yrow4 * YWS + 4 + 8 * yj4;  // copy c sits c * YCOPY further
         unsigned char ypre[YLOADS];
@@ -452,7 +455,7 @@ void k_c1c2(const FusedArgs a)
             // first halo pixel of this producer's rows
             const int xa = tp.tx * TW - 4, ya = tp.ty * TH - 4 + (warm ? 4 + WARM_ROWS * p : PROD_ROWS * p);
             const uint8_t *yf = a.y + (size_t)tp.f * a.frame_stride;
-            pre_dwords = xa >= 0 && xa + YWC + 4 <= W && ya >= 0 && ya + 9 <= H;
+            pre_dwords = xa >= 0 && xa + YWC + 4 <= W && ya >= 0 && ya + YROWS <= H;
             if (pre_dwords) {  // inside the frame: raw bytes, turned into x - 128 when they are written to LDS
                 const uint8_t *org = yf + (size_t)ya * W + xa;
                 if (ylane4) __builtin_memcpy(ypre4, org + goff4, 12);
@@ -473,12 +476,12 @@ void k_c1c2(const FusedArgs a)
         advance(nxt);
         // this wave's share of the C2 stage of tile n-1: the last rows of its consumer's block
         auto c2_share = [&](int n) {
-            if constexpr (C2_CONS_ROWS < 8) {
+            if constexpr (C2_CONS_ROWS < C2_BLOCK_ROWS) {
                 if (n >= 1) {
-                    C2Acc<8 - C2_CONS_ROWS> acc;
-                    c2_mfma<EXACT, 8 - C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
+                    C2Acc<C2_BLOCK_ROWS - C2_CONS_ROWS> acc;
+                    c2_mfma<EXACT, C2_BLOCK_ROWS - C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
                                                      [] {});
-                    c2_store<PATH, 8 - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
+                    c2_store<PATH, C2_BLOCK_ROWS - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
                                                       a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
                 }
             }

@@ -26,12 +26,17 @@ struct Requant {
 // Kernel A: Y -> C1 -> (C2_1 || C2_2) -> conc1 in HBM.  Persistent 768-thread workgroups walk
 // 16 x 32 output tiles; four producer waves fill a double-buffered C1 tile, eight consumer waves
 // run the C2 stage on the other buffer.
+#ifndef QCNN_A_TH
+#define QCNN_A_TH 20
+#endif
 namespace ka {
-constexpr int TH = 16, TW = 32;
+constexpr int TH = QCNN_A_TH, TW = 32;        // TH: a multiple of 4 (four producers, two row blocks of consumers)
+static_assert(TH % 4 == 0 && TH >= 8, "tile height");
 constexpr int C1R = TH + 4, C1C = TW + 4;  // C1 output region held in LDS (halo 2)
 constexpr int PROD_ROWS = C1R / 4;         // C1 region rows per producer wave (cold tile: all 20 rows computed)
 constexpr int WARM_ROWS = TH / 4;          // the same for a warm tile (rows 4..19; rows 0..3 copied from the tile above)
-constexpr int YWR = PROD_ROWS + 5, YWC = TW + 8;  // private Y tile of one producer (halo 4 + 1 slack row)
+constexpr int YROWS = PROD_ROWS + 4;       // Y rows a producer needs for its C1 rows (halo 2 + 2)
+constexpr int YWR = YROWS + 1, YWC = TW + 8;  // private Y tile of one producer (+ 1 slack row)
 constexpr int YWS = YWC + 8;               // row stride of one LDS copy of it: 4 bytes lead-in, 4 tail
 constexpr int YCOPY = YWR * YWS;           // bytes of one copy; a producer keeps 4, shifted by 0..3 bytes
 constexpr int SC1_BYTES = C1R * C1C * 64;

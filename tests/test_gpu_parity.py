@@ -73,8 +73,8 @@ def test_golden_case_layered_and_fused(qp, golden_dir):
         _check_fused(net, y, case["rec"], case["conc1"])
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 7), (16, 32), (18, 30), (17, 31), (19, 33), (36, 60), (37, 61),
-                                   (67, 131), (240, 416)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 7), (16, 32), (18, 30), (17, 31), (19, 33), (20, 32), (21, 31), (36, 60),
+                                   (37, 61), (40, 64), (41, 65), (59, 97), (67, 131), (240, 416)])
 def test_fused_matches_oracle_on_ragged_sizes(shape):
     qp = 37
     m = synth.synth_model(qp)
