@@ -1,7 +1,7 @@
 // Kernel A of the fused forward pass: Y -> I1.ppro -> C1 -> requant -> (C2_1 || C2_2) -> requant ->
 // concat, written to HBM as [H][W][48] int8 (see fused_common.h for the overall design).
 //
-// Persistent, wave-specialised: one 768-thread workgroup per CU walks a list of 16 x 32 output
+// Persistent, wave-specialised: one 768-thread workgroup per CU walks a list of 20 x 32 output
 // tiles.  Waves 0-3 are PRODUCERS (Y tile, im2col, C1 MFMAs, C1 requant epilogue: VALU-heavy),
 // waves 4-11 are CONSUMERS (C2 MFMAs, C2 requant epilogue: MFMA-heavy).  Waves w, w+4 and w+8 share
 // a SIMD, so each SIMD always has VALU-bound and MFMA-bound instruction streams to interleave: a
@@ -9,8 +9,8 @@
 // with tile n while the consumers read buffer (n-1)&1; one workgroup barrier ends each step.
 // A workgroup walks its tiles DOWN a 32-pixel column of the frame: the top 4 rows of the C1 region
 // of a tile are the bottom 4 rows of the tile above it, so the producers copy them from the other
-// LDS buffer and compute 16 new rows instead of 20 (a "warm" tile; the first tile of a workgroup
-// and the top tile of a column are "cold" and compute all 20).
+// LDS buffer and compute 20 new rows instead of 24 (a "warm" tile; the first tile of a workgroup
+// and the top tile of a column are "cold" and compute all 24).
 #include "fused_common.h"
 
 namespace qcnn {
@@ -219,7 +219,7 @@ __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *b
     });
 }
 
-// Rows of a consumer's 8 x 16 block that the consumer itself computes; the PRODUCER wave on the same
+// Rows of a SIMD's 10 x 16 block (C2_BLOCK_ROWS x 16) that its consumers compute themselves; the PRODUCER wave on the same
 // SIMD would compute the rest after its C1 work.  Measured: with 7 the step does not get shorter (the
 // MFMA pipe and the vector issue port are shared by the two waves either way, and the producer's
 // one-row share reuses no fragment), so the consumer keeps all 8.
@@ -233,7 +233,7 @@ constexpr int C2_CONS_ROWS = C2_CONS_ROWS_N;
 #ifndef C2_SHARE_FIRST
 #define C2_SHARE_FIRST 1
 #endif
-// Consumer waves per SIMD.  With two, consumer 0 takes the upper half of the SIMD's 8 x 16 block and stores a
+// Consumer waves per SIMD.  With two, consumer 0 takes the upper half of the SIMD's 10 x 16 block and stores a
 // tile at the start of the next step (as the single consumer does), consumer 1 takes the lower half and stores
 // at the end of its own step: one of them always has matrix instructions to issue while the other requantises.
 #ifndef C2_CONSUMERS_N
@@ -342,7 +342,7 @@ void k_c1c2(const FusedArgs a)
 
     // C2 constants of this lane, used by the consumer and by the producer's share of the C2 rows
     const int c = lane & 15, g = lane >> 4;
-    const int blk = wv & 3;  // the 8 x 16 output block of this SIMD's consumer / producer pair
+    const int blk = wv & 3;  // the C2_BLOCK_ROWS x 16 output block of this SIMD's consumers and producer
     const int cb = (blk & 1) * 16, R0 = (blk >> 1) * C2_BLOCK_ROWS;
     const v4i *w22 = reinterpret_cast<const v4i *>(sW) + lane;
     const v4i *w21 = reinterpret_cast<const v4i *>(sW + (PackedOffsets::C2W21 - PackedOffsets::C2W22)) + lane;
@@ -590,7 +590,7 @@ void k_c1c2(const FusedArgs a)
                     });
                 };
                 if (warm) {
-                    // region rows 0..3 = rows 16..19 of the tile above, which sits in the other buffer: a
+                    // region rows 0..3 = rows TH..TH+3 of the tile above, which sits in the other buffer: a
                     // straight copy of 4 x 36 x 64 bytes (the chunk rotation depends on the column only)
                     const v4i *src = reinterpret_cast<const v4i *>(smem + ((n - 1) & 1) * SC1_BYTES) + TH * C1C * 4;
                     v4i *dst = reinterpret_cast<v4i *>(buf);
@@ -620,7 +620,7 @@ void k_c1c2(const FusedArgs a)
         }
     } else {
         // =============================== consumer ===============================
-        // rows R0c .. R0c + C2_ROWS - 1 of the SIMD's 8 x 16 block of tile n-1.
+        // rows R0c .. R0c + C2_ROWS - 1 of the SIMD's block of tile n-1.
         // A deferring consumer, in step n, issues the first LDS reads of tile n-1, requantises and stores tile
         // n-2 (whose accumulators it still holds) while they travel, then runs the MFMAs of tile n-1.  The second
         // consumer of a SIMD (and the float pipeline, which needs its registers for the requant) stores a tile

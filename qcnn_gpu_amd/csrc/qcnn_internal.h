@@ -24,7 +24,8 @@ struct Requant {
 
 // ---- fused kernel geometry -------------------------------------------------------------
 // Kernel A: Y -> C1 -> (C2_1 || C2_2) -> conc1 in HBM.  Persistent 768-thread workgroups walk
-// 16 x 32 output tiles; four producer waves fill a double-buffered C1 tile, eight consumer waves
+// 20 x 32 output tiles (the tallest that two C1 tiles, the weights and the Y tiles leave room for in 160 KiB
+// of LDS); four producer waves fill a double-buffered C1 tile, eight consumer waves
 // run the C2 stage on the other buffer.
 #ifndef QCNN_A_TH
 #define QCNN_A_TH 20
@@ -38,7 +39,15 @@ constexpr int WARM_ROWS = TH / 4;          // the same for a warm tile (rows 4..
 constexpr int YROWS = PROD_ROWS + 4;       // Y rows a producer needs for its C1 rows (halo 2 + 2)
 constexpr int YWR = YROWS + 1, YWC = TW + 8;  // private Y tile of one producer (+ 1 slack row)
 constexpr int YWS = YWC + 8;               // row stride of one LDS copy of it: 4 bytes lead-in, 4 tail
-constexpr int YCOPY = YWR * YWS;           // bytes of one copy; a producer keeps 4, shifted by 0..3 bytes
+// bytes of one copy; a producer keeps 4, shifted by 0..3 bytes.  Pixel j of a 32-pixel group reads copy j & 3 at dword
+// (j >> 2) of its row: with the copies 8 dwords apart modulo the 64 banks the 32 lanes hit 32 different banks.
+constexpr int ycopy_bytes(int raw)
+{
+    int n = (raw + 15) / 16 * 16;
+    while (n % 256 != 32 && n % 256 != 224) n += 16;
+    return n;
+}
+constexpr int YCOPY = ycopy_bytes(YWR * YWS);
 constexpr int SC1_BYTES = C1R * C1C * 64;
 constexpr int SYW_BYTES = 4 * YCOPY;
 constexpr int SW_BYTES = 43 * 1024;        // the 25 + 18 C2 A fragments
