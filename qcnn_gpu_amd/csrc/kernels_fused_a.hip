@@ -142,9 +142,23 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
             unsigned d0, d1, d2;
             quant_row(y, d0, d1, d2);
             unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+#ifdef QCNN_CONC_STORE_POLICY  // experiment builds: cache policy bits of the conc1 stores (1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt)
+            typedef unsigned v3u __attribute__((ext_vector_type(3)));
+            const v3u d = {d0, d1, d2};
+#if QCNN_CONC_STORE_POLICY == 1
+            asm volatile("global_store_dwordx3 %0, %1, off nt" ::"v"(dst), "v"(d) : "memory");
+#elif QCNN_CONC_STORE_POLICY == 2
+            asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(dst), "v"(d) : "memory");
+#elif QCNN_CONC_STORE_POLICY == 3
+            asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" ::"v"(dst), "v"(d) : "memory");
+#else
+            asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(d) : "memory");
+#endif
+#else
             dst[0] = d0;
             dst[1] = d1;
             dst[2] = d2;
+#endif
         }
     } else {
 #pragma unroll
