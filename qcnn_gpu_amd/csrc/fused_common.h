@@ -115,6 +115,25 @@ __device__ __forceinline__ void requant12_int(const v4i &a, const v4i &b, const 
           "s"(qab.mulk), "s"(qc.mulk));
 }
 
+// The same for two dwords with one requantiser (the 8 C2_1 channels a lane owns when its wave runs C2_1 alone).
+__device__ __forceinline__ void requant8_int(const v4i &a, const v4i &b, const Requant &q, unsigned &pa, unsigned &pb)
+{
+    int ta, tb;
+#define QCNN_REQ8_STEP(A, B, SEL, UNUSED)                                                                            \
+    "v_mad_i32_i24 %2, " A ", %12, 0 clamp\n\t"                                                                       \
+    "v_mad_i32_i24 %3, " B ", %12, 0 clamp\n\t"                                                                       \
+    "v_max_i32_sdwa %0, sext(%2), 0 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:BYTE_3 src1_sel:DWORD\n\t"         \
+    "v_max_i32_sdwa %1, sext(%3), 0 dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+    asm(QCNN_REQ8_STEP("%4", "%8", "BYTE_0", "UNUSED_PAD")
+        QCNN_REQ8_STEP("%5", "%9", "BYTE_1", "UNUSED_PRESERVE")
+        QCNN_REQ8_STEP("%6", "%10", "BYTE_2", "UNUSED_PRESERVE")
+        QCNN_REQ8_STEP("%7", "%11", "BYTE_3", "UNUSED_PRESERVE")
+        "s_nop 0"
+        : "=&v"(pa), "=&v"(pb), "=&v"(ta), "=&v"(tb)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "s"(q.mulk));
+#undef QCNN_REQ8_STEP
+}
+
 // requant12_int for models whose C2 accumulators may leave the signed 24-bit range (the load-time proof of the
 // two-instruction form fails on the accumulator bounds only): s is first clamped to [-1, blu + q.bias], three
 // instructions per channel.  Every s above blu + q.bias requantises to 127 like blu itself and every negative s

@@ -15,48 +15,54 @@
 
 namespace qcnn {
 
-// Load plan of the C2 stage for a wave that owns ROWS output rows x 16 columns x 48 channels.  Step
-// I = IN s + yy issues every MFMA that uses the B fragment of (input row yy, kernel column s) of the
-// wave's IN = ROWS + 4 input rows.  The LDS reads (5 IN B fragments, 25 C2_2 and 18 C2_1 A fragments)
-// are numbered in the order the steps first need them; need[I] is the number of reads that must have
-// been issued before step I.  The kernel issues the reads of step I + C2_PREFETCH while it runs the
-// MFMAs of step I.
-template <int ROWS>
+// Load plan of the C2 stage for a wave that owns ROWS output rows x 16 columns of the convolutions in CONV (bit 0:
+// C2_2, bit 1: C2_1; both: 48 channels).  A step issues every MFMA that uses the B fragment of (input row yy, kernel
+// column s) of the wave's IN = ROWS + 4 input rows (C2_1 alone needs kernel columns 1..3 and input rows 1..IN-2
+// only).  The LDS reads (B fragments, 25 C2_2 and 18 C2_1 A fragments) are numbered in the order the steps first
+// need them; need[I] is the number of reads that must have been issued before step I.  The kernel issues the
+// reads of step I + C2_PREFETCH while it runs the MFMAs of step I.
+template <int ROWS, int CONV = 3>
 struct C2Plan {
-    static constexpr int IN = ROWS + 4, STEPS = 5 * IN, ITEMS = STEPS + 25 + 18;
+    static constexpr int IN = ROWS + 4, MAXSTEPS = 5 * IN, ITEMS = MAXSTEPS + 25 + 18;  // (upper bounds)
     int kind[ITEMS];  // 0: B fragment (s, yy); 1: C2_2 A fragment (s, r); 2: C2_1 A fragment (s-1, r-1, t)
     int a0[ITEMS], a1[ITEMS], a2[ITEMS];
-    int need[STEPS];
+    int need[MAXSTEPS], step_s[MAXSTEPS], step_yy[MAXSTEPS];
     int iB[5][IN], i22[5][5], i21[3][3][2];
-    int n;
+    int n, steps;
 };
-template <int ROWS>
-constexpr C2Plan<ROWS> make_c2_plan()
+template <int ROWS, int CONV>
+constexpr C2Plan<ROWS, CONV> make_c2_plan()
 {
-    C2Plan<ROWS> p{};
-    int n = 0;
-    for (int s = 0; s < 5; ++s)
+    C2Plan<ROWS, CONV> p{};
+    int n = 0, steps = 0;
+    for (int s = 0; s < 5; ++s) {
+        if (!(CONV & 1) && (s < 1 || s > 3)) continue;
         for (int yy = 0; yy < ROWS + 4; ++yy) {
+            if (!(CONV & 1) && (yy < 1 || yy > ROWS + 2)) continue;
             p.iB[s][yy] = n;
             p.kind[n] = 0, p.a0[n] = s, p.a1[n] = yy, ++n;
             if (yy < 5) {  // kernel row r = yy is first used here (output row 0)
-                p.i22[s][yy] = n;
-                p.kind[n] = 1, p.a0[n] = s, p.a1[n] = yy, ++n;
-                if (s >= 1 && s <= 3 && yy >= 1 && yy <= 3)
+                if (CONV & 1) {
+                    p.i22[s][yy] = n;
+                    p.kind[n] = 1, p.a0[n] = s, p.a1[n] = yy, ++n;
+                }
+                if ((CONV & 2) && s >= 1 && s <= 3 && yy >= 1 && yy <= 3)
                     for (int t = 0; t < 2; ++t) {
                         p.i21[s - 1][yy - 1][t] = n;
                         p.kind[n] = 2, p.a0[n] = s - 1, p.a1[n] = yy - 1, p.a2[n] = t, ++n;
                     }
             }
-            p.need[s * (ROWS + 4) + yy] = n;
+            p.step_s[steps] = s, p.step_yy[steps] = yy;
+            p.need[steps++] = n;
         }
-    p.n = n;
+    }
+    p.n = n, p.steps = steps;
     return p;
 }
-template <int ROWS>
+template <int ROWS, int CONV = 3>
 struct C2PlanOf {
-    static constexpr C2Plan<ROWS> P = make_c2_plan<ROWS>();
-    static_assert(P.n == C2Plan<ROWS>::ITEMS, "B fragments + 25 + 18 A fragments");
+    static constexpr C2Plan<ROWS, CONV> P = make_c2_plan<ROWS, CONV>();
+    static_assert(CONV != 3 || P.n == C2Plan<ROWS, CONV>::ITEMS, "B fragments + 25 + 18 A fragments");
 };
 #ifndef C2_PREFETCH_N
 #define C2_PREFETCH_N 4
@@ -69,13 +75,13 @@ constexpr int C2_PREFETCH = C2_PREFETCH_N;  // steps of look-ahead of the LDS re
 // puts other work between them and the MFMAs, so they have landed by then).
 constexpr int C2_PREFETCH_START = C2_PREFETCH_START_N;
 static_assert(C2_PREFETCH_START >= C2_PREFETCH, "the start covers at least the steady look-ahead");
-template <int ROWS>
+template <int ROWS, int CONV = 3>
 constexpr int c2_issued(int I)  // reads issued once step I has issued its own (I = -1: before step 0)
 {
-    constexpr int STEPS = C2Plan<ROWS>::STEPS;
-    const int start = C2PlanOf<ROWS>::P.need[C2_PREFETCH_START - 1];
+    constexpr int STEPS = C2PlanOf<ROWS, CONV>::P.steps;
+    const int start = C2PlanOf<ROWS, CONV>::P.need[C2_PREFETCH_START - 1];
     if (I < 0) return start;
-    const int n = C2PlanOf<ROWS>::P.need[I + C2_PREFETCH < STEPS ? I + C2_PREFETCH : STEPS - 1];
+    const int n = C2PlanOf<ROWS, CONV>::P.need[I + C2_PREFETCH < STEPS ? I + C2_PREFETCH : STEPS - 1];
     return n > start ? n : start;
 }
 
@@ -109,7 +115,7 @@ struct C2Acc {
 // Requant of the accumulators and the store into conc1 (frame `concf`): rows R0 .. R0+ROWS-1, columns
 // cb .. cb+15 of the tile at (x0, y0).  Lane (pixel c, g) owns channels 4g..4g+3 of each 16-channel
 // tile = 12 consecutive bytes at position 12g of the pixel in the internal channel order.
-template <int MODE, int ROWS>
+template <int MODE, int ROWS, int CONV = 3>
 __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb, int c, int g, const C2Consts &k, int8_t *concf,
                                          int x0, int y0, int H, int W)
 {
@@ -121,8 +127,13 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
     const size_t row_bytes = (size_t)conc_wp(W) * 48;  // row y sits y * row_bytes further
     int8_t *out = concf + (size_t)(gy0 + 2) * row_bytes + (size_t)(gx + 2) * 48 + 12 * g;
     constexpr bool EXACT = MODE == A_FLOAT;
+    static_assert(CONV == 3 || MODE == A_INT, "single-convolution waves exist on the integer path only");
     auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
-        if constexpr (MODE == A_INT) {
+        if constexpr (MODE == A_INT && CONV == 1) {
+            d2 = requant4_int(acc.a22[y][0], acc.a22[y][1], acc.a22[y][2], acc.a22[y][3], k.q22);
+        } else if constexpr (MODE == A_INT && CONV == 2) {
+            requant8_int(acc.a21[0][y], acc.a21[1][y], k.q21, d0, d1);
+        } else if constexpr (MODE == A_INT) {
             requant12_int(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, d0, d1, d2);
         } else if constexpr (MODE == A_WIDE) {
             requant12_wide(acc.a21[0][y], acc.a21[1][y], acc.a22[y], k.q21, k.q22, k.q21.blu + k.q21.bias, k.q22.blu + k.q22.bias, d0,
@@ -142,6 +153,14 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
             unsigned d0, d1, d2;
             quant_row(y, d0, d1, d2);
             unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+            if constexpr (CONV == 1) {
+                dst[2] = d2;
+                continue;
+            } else if constexpr (CONV == 2) {
+                dst[0] = d0;
+                dst[1] = d1;
+                continue;
+            }
 #ifdef QCNN_CONC_STORE_POLICY  // experiment builds: cache policy bits of the conc1 stores (1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt)
             typedef unsigned v3u __attribute__((ext_vector_type(3)));
             const v3u d = {d0, d1, d2};
@@ -167,9 +186,11 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
             quant_row(y, d0, d1, d2);
             if (gy0 + y < H && gx < W) {
                 unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
-                dst[0] = d0;
-                dst[1] = d1;
-                dst[2] = d2;
+                if constexpr (CONV & 2) {
+                    dst[0] = d0;
+                    dst[1] = d1;
+                }
+                if constexpr (CONV & 1) dst[2] = d2;
             }
         }
     }
@@ -180,18 +201,18 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
 // LDS column = output column + s (the 3x3 taps are r-1, s-1 of the 5x5 window).  The LDS reads of
 // the first steps are issued, then `between()` runs (it may still read the previous contents of
 // `acc`), then the accumulators are set to the biases and the MFMA steps run.
-template <bool EXACT, int ROWS, typename F>
+template <bool EXACT, int ROWS, int CONV = 3, typename F>
 __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *buf, int R0, int cb, int c, int g, const v4i *w22,
                                         const v4i *w21, const C2Consts &k, F &&between)
 {
     using namespace ka;
-    using PO = C2PlanOf<ROWS>;  // PO::P is the plan
-    constexpr int IN = C2Plan<ROWS>::IN, STEPS = C2Plan<ROWS>::STEPS;
+    using PO = C2PlanOf<ROWS, CONV>;  // PO::P is the plan
+    constexpr int IN = C2Plan<ROWS, CONV>::IN, STEPS = PO::P.steps;
     const unsigned char *rowbase = buf + (R0 * C1C + cb + c) * 64;
     const unsigned char *colbase[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) colbase[s] = rowbase + s * 64 + swz(g, cb + c + s);
-    v4i item[C2Plan<ROWS>::ITEMS];
+    v4i item[C2Plan<ROWS, CONV>::ITEMS];
     auto issue = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
         if constexpr (PO::P.kind[J] == 0)
@@ -201,35 +222,37 @@ __device__ __forceinline__ void c2_mfma(C2Acc<ROWS> &acc, const unsigned char *b
         else
             item[J] = w21[((PO::P.a0[J] * 3 + PO::P.a1[J]) * 2 + PO::P.a2[J]) * 64];
     };
-    static_range<0, c2_issued<ROWS>(-1)>(issue);
+    static_range<0, c2_issued<ROWS, CONV>(-1)>(issue);
     __builtin_amdgcn_sched_barrier(0);
     between();
     __builtin_amdgcn_sched_barrier(0);
     C2_STAMP();
 #pragma unroll
     for (int y = 0; y < ROWS; ++y) {
-        acc.a21[0][y] = k.b0;
-        acc.a21[1][y] = k.b1;
-        acc.a22[y] = k.b2;
+        if constexpr (CONV & 2) {
+            acc.a21[0][y] = k.b0;
+            acc.a21[1][y] = k.b1;
+        }
+        if constexpr (CONV & 1) acc.a22[y] = k.b2;
     }
     static_for<STEPS>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
-        constexpr int s = I / IN, yy = I % IN;
-        static_range<c2_issued<ROWS>(I - 1), c2_issued<ROWS>(I)>(issue);
+        constexpr int s = PO::P.step_s[I], yy = PO::P.step_yy[I];
+        static_range<c2_issued<ROWS, CONV>(I - 1), c2_issued<ROWS, CONV>(I)>(issue);
         const v4i B = item[PO::P.iB[s][yy]];
         static_for<5>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             constexpr int y = yy - r;
             if constexpr (y >= 0 && y < ROWS) {
-                acc.a22[y] = mfma16(item[PO::P.i22[s][r]], B, acc.a22[y]);
-                if constexpr (s >= 1 && s <= 3 && r >= 1 && r <= 3) {
+                if constexpr (CONV & 1) acc.a22[y] = mfma16(item[PO::P.i22[s][r]], B, acc.a22[y]);
+                if constexpr ((CONV & 2) && s >= 1 && s <= 3 && r >= 1 && r <= 3) {
                     acc.a21[0][y] = mfma16(item[PO::P.i21[s - 1][r - 1][0]], B, acc.a21[0][y]);
                     acc.a21[1][y] = mfma16(item[PO::P.i21[s - 1][r - 1][1]], B, acc.a21[1][y]);
                 }
             }
         });
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (yy == IN - 1) C2_STAMP();
+        if constexpr (I + 1 == STEPS || PO::P.step_s[I + 1 < STEPS ? I + 1 : I] != s) C2_STAMP();
     });
 }
 
@@ -276,6 +299,11 @@ constexpr int C2_CONSUMERS = C2_CONSUMERS_N;
 #ifndef C2_PRIO_PRODUCER
 #define C2_PRIO_PRODUCER -1
 #endif
+// Experiment: the two consumers of a SIMD split its block by convolution instead of by rows (1: the older wave
+// takes C2_2, 2: C2_1); integer path only.
+#ifndef C2_SPLIT_CONV
+#define C2_SPLIT_CONV 0
+#endif
 template <int P>
 __device__ __forceinline__ void set_prio()
 {
@@ -283,7 +311,6 @@ __device__ __forceinline__ void set_prio()
 }
 static_assert(C2_CONSUMERS == 1 || (C2_CONSUMERS == 2 && C2_CONS_ROWS == C2_BLOCK_ROWS && C2_BLOCK_ROWS % 2 == 0),
               "two consumers split all rows of the block");
-constexpr int C2_ROWS = C2_CONS_ROWS / C2_CONSUMERS;      // rows of one consumer wave
 constexpr int A_WAVES = 4 + 4 * C2_CONSUMERS, A_THREADS = 64 * A_WAVES;
 
 // End of a pipeline step: every LDS write of this wave has landed, then the workgroup barrier.
@@ -639,16 +666,18 @@ void k_c1c2(const FusedArgs a)
         // n-2 (whose accumulators it still holds) while they travel, then runs the MFMAs of tile n-1.  The second
         // consumer of a SIMD (and the float pipeline, which needs its registers for the requant) stores a tile
         // right after its MFMAs.
-        auto consumer = [&](auto deferc, int half) {
+        // (convc / rowsc: the convolutions and the number of rows of the block this wave computes)
+        auto consumer = [&](auto deferc, int half, auto convc, auto rowsc) {
             constexpr bool DEFER = decltype(deferc)::value;
+            constexpr int CONV = decltype(convc)::value, C2_ROWS = decltype(rowsc)::value;
             const int R0c = R0 + half * C2_ROWS;
             C2Acc<C2_ROWS> acc;
             TilePos held = pos;  // the tile whose results `acc` holds
             bool have = false;
             auto store_held = [&] {
                 if (have)
-                    c2_store<PATH, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
-                                             held.ty * TH, H, W);
+                    c2_store<PATH, C2_ROWS, CONV>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
+                                                   held.ty * TH, H, W);
             };
             auto store_then_release = [&] {
                 store_held();
@@ -663,16 +692,16 @@ void k_c1c2(const FusedArgs a)
 #else
                     const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
                     if constexpr (DEFER) {
-                        c2_mfma<EXACT, C2_ROWS>(acc, buf, R0c, cb, c, g, w22, w21, kc, store_then_release);
+                        c2_mfma<EXACT, C2_ROWS, CONV>(acc, buf, R0c, cb, c, g, w22, w21, kc, store_then_release);
                         set_prio<C2_PRIO_D_VALU>();
                         held = pos;
                         have = true;
                     } else {
                         set_prio<C2_PRIO_N_MFMA>();
-                        c2_mfma<EXACT, C2_ROWS>(acc, buf, R0c, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
+                        c2_mfma<EXACT, C2_ROWS, CONV>(acc, buf, R0c, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
                         set_prio<C2_PRIO_N_VALU>();
-                        c2_store<PATH, C2_ROWS>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
-                                                 pos.ty * TH, H, W);
+                        c2_store<PATH, C2_ROWS, CONV>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
+                                                       pos.ty * TH, H, W);
                     }
 #endif
                     advance(pos);
@@ -684,17 +713,26 @@ void k_c1c2(const FusedArgs a)
             }
             if constexpr (DEFER) store_held();
         };
+        constexpr std::integral_constant<int, 3> both{};
+        constexpr std::integral_constant<int, C2_CONS_ROWS / C2_CONSUMERS> part{};  // rows of one consumer wave
         if constexpr (EXACT) {
-            consumer(std::false_type{}, (wv - 4) >> 2);
+            consumer(std::false_type{}, (wv - 4) >> 2, both, part);
         } else if constexpr (C2_CONSUMERS == 1) {
-            consumer(std::true_type{}, 0);
+            consumer(std::true_type{}, 0, both, part);
+        } else if constexpr (C2_SPLIT_CONV != 0 && PATH == A_INT) {
+            // experiment: the two consumers of a SIMD split the block by convolution, all its rows each
+            constexpr std::integral_constant<int, C2_BLOCK_ROWS> all{};
+            constexpr std::integral_constant<int, C2_SPLIT_CONV == 1 ? 1 : 2> conv_old{};  // 1: the older wave takes C2_2
+            constexpr std::integral_constant<int, C2_SPLIT_CONV == 1 ? 2 : 1> conv_young{};
+            if (wv < 8) consumer(std::false_type{}, 0, conv_old, all);
+            else consumer(std::true_type{}, 0, conv_young, all);
         } else {
 #if C2_DEFER_YOUNGER
-            if (wv < 8) consumer(std::false_type{}, 0);
-            else consumer(std::true_type{}, 1);
+            if (wv < 8) consumer(std::false_type{}, 0, both, part);
+            else consumer(std::true_type{}, 1, both, part);
 #else
-            if (wv < 8) consumer(std::true_type{}, 0);
-            else consumer(std::false_type{}, 1);
+            if (wv < 8) consumer(std::true_type{}, 0, both, part);
+            else consumer(std::false_type{}, 1, both, part);
 #endif
         }
     }
