@@ -143,6 +143,8 @@ def adversarial_model(kind: str) -> StaticModel:
     'heavy'    : C1 and C2 at full magnitude on every tap with the usual requantisers and small biases: the C2_2
                  accumulators pass 2^24 on bright input (where the reference's float conversion rounds) and
                  -2^23 on the mixed-sign channels; C3 and C4 as trained.  Kernel A takes its clamped integer form.
+    'c4big'    : the usual network with a C4 multiplier so large that applyRes_y's 32-bit product wraps (the reference
+                 computes it in unsigned arithmetic): kernel B must replay the literal form, kernel A keeps integers.
     'balanced' : dense weights of both signs in equal numbers, as large as keep the sum of the positive and
                  the sum of the negative weights of a channel, times 127, below 2^23 each while sum|w| * 127
                  passes 2^23 in C2_1 and C2_2: activations are never negative, so the accumulators stay
@@ -158,6 +160,9 @@ def adversarial_model(kind: str) -> StaticModel:
             lp.b = np.full(lp.b.shape, (1 << 24) + 3 if l == 2 else 12345, np.int32)
             if l < 5:
                 lp.blu, lp.mul, lp.shift = (1 << 25), 1, 18
+        return m
+    if kind == "c4big":
+        m.layers[5].mul, m.layers[5].shift = 3_000_017, 24
         return m
     if kind == "heavy":
         for l in (0, 1, 2):

@@ -110,7 +110,7 @@ def test_fused_float_pipeline_variant(qp):
         _check_fused(net, y, rec_o, taps_o["conc1"])
 
 
-@pytest.mark.parametrize("kind", ["maxmag", "identity", "wide", "balanced", "heavy"])
+@pytest.mark.parametrize("kind", ["maxmag", "identity", "wide", "balanced", "heavy", "c4big"])
 def test_adversarial_models(kind):
     m = synth.adversarial_model(kind)
     mb = m.to_nchw_vect_c_bytes()
@@ -128,6 +128,8 @@ def test_adversarial_models(kind):
             assert net.is_exact               # accumulators can pass 2^24: float pipeline is selected
         if kind in ("wide", "balanced"):
             assert net.arith_paths == (0, 0)  # inside the 24-bit operand range: integer requantiser
+        if kind == "c4big":
+            assert net.arith_paths == (0, 1)  # integers in kernel A, the literal (wrapping) residual arithmetic in kernel B
         if kind == "heavy":
             # C2 accumulator bounds beyond 2^24, everything else in range: clamped integers in kernel A, plain in B
             pos = [np.maximum(lp.w.astype(np.int64), 0).reshape(lp.w.shape[0], -1).sum(1).max() * 127 for lp in m.layers]
