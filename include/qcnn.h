@@ -115,7 +115,7 @@ int qcnn_clip_reserve(qcnn_t *e, int nframes, int with_sse);
 /* Frames that one kernel launch of qcnn_forward_blu_batch covers (the loop of
  * inference/kernel.cu:91-97 has no such knob: it is the price of the intermediate conc1 image,
  * 48*height*width bytes of device scratch per frame of a launch).  set > 0 changes it, current
- * (may be NULL) receives the value in force.  Default: as many frames as fit 2 GiB, at most 16. */
+ * (may be NULL) receives the value in force.  Default: as many frames as fit 8 GiB, at most 16. */
 int qcnn_batch_group(qcnn_t *e, int set, int *current);
 
 /* The same pass run layer by layer through the qcnn_op_* kernels below, materialising every

@@ -578,9 +578,10 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY_E(hipMemsetAsync(e->conc1_int, 0, conc_bytes(height, width), e->stream));
     e->conc_frames = 1;
     {
-        // frames per launch of the batch entry point: as many as fit a scratch budget (default 2 GiB)
+        // frames per launch of the batch entry point: up to 16, as many as fit a scratch budget of 8 GiB (of the
+        // device's 288: sixteen 3840 x 2160 frames take 6.4 GB of conc1 and run 1.8 % faster than five)
         const char *gb = getenv("QCNN_BATCH_GROUP");
-        const long long fit = (2ll << 30) / (long long)conc_bytes(height, width);
+        const long long fit = (8ll << 30) / (long long)conc_bytes(height, width);
         e->group = gb ? atoi(gb) : (int)(fit < 1 ? 1 : fit > 16 ? 16 : fit);
         if (e->group < 1) e->group = 1;
     }
