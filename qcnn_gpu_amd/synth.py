@@ -172,10 +172,12 @@ def adversarial_model(kind: str) -> StaticModel:
             w = np.empty((co, per), np.int64)
             for k in range(co):
                 i = np.arange(per)
-                if k % 2 == 0:
+                if l == 0:
+                    w[k] = 127 if k % 4 != 3 else -128               # three in four C1 channels saturate on white input
+                elif k % 2 == 0:
                     w[k] = 127                                       # all-positive channel
                 else:
-                    w[k] = np.where((i * 7 + k) % 10 < 3, 127, -128)  # 70 % negative
+                    w[k] = np.where((i * 7 + k) % 20 < 3, 127, -128)  # 85 % negative
             lp.w = w.astype(np.int8).reshape(lp.w.shape)
             lp.b = ((np.arange(co) % 9 - 4) * 3000 + 17).astype(np.int32)
         return m

@@ -121,7 +121,7 @@ def test_c_and_numpy_oracles_agree(qp, shape):
         assert np.array_equal(taps_n["u"][l], taps_c["u"][l]), l
 
 
-@pytest.mark.parametrize("kind", ["maxmag", "identity"])
+@pytest.mark.parametrize("kind", ["maxmag", "identity", "heavy", "c4big"])
 def test_oracles_agree_on_adversarial_models(kind):
     m = synth.adversarial_model(kind)
     for frame in (np.zeros((9, 20), np.uint8), np.full((9, 20), 255, np.uint8),
@@ -134,6 +134,10 @@ def test_oracles_agree_on_adversarial_models(kind):
     if kind == "maxmag":
         # the point of this model: C2_2 accumulators beyond 2^24, where float32 rounding matters
         assert np.abs(taps_c["u"][2]).max() > 2 ** 24
+    if kind == "heavy":
+        # ... and of this one: the same on a white frame with the usual requantisers (every such value clips to 127)
+        _, taps_w = c_oracle.forward_blu(m.to_nchw_vect_c_bytes(), np.full((9, 20), 255, np.uint8), True)
+        assert taps_w["u"][2].max() > 2 ** 24 and taps_w["u"][2].min() < -(2 ** 23)
 
 
 @pytest.mark.parametrize("qp", [22, 27, 32, 37])
