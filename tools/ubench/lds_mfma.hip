@@ -87,7 +87,7 @@ int main()
     unsigned x = 12345;
     for (auto &v : h) v = (int)(x = x * 1664525u + 1013904223u);
     hipMemcpy(init, h.data(), 40 * 1024, hipMemcpyHostToDevice);
-    for (int waves : {2, 3}) {
+    for (int waves : {1, 2, 3}) {
         run<0, 8>(waves, d, sink, init);
         run<2, 8>(waves, d, sink, init);
         run<4, 8>(waves, d, sink, init);
