@@ -122,6 +122,12 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
 #ifdef QCNN_ABL_L2STORES  // diagnostic builds only (garbage results): every workgroup keeps storing one tile, which stays in L2
     x0 = (blockIdx.x % 60) * ka::TW, y0 = (blockIdx.x / 60) * ka::TH;
 #endif
+#ifdef QCNN_ABL_LINEARSTORES  // diagnostic builds only (garbage results): lane l stores the 12 bytes at 12 l of the wave's 768
+    {
+        const int l = c + 16 * g;
+        c = l >> 2, g = l & 3;
+    }
+#endif
     const int gx = x0 + cb + c, gy0 = y0 + R0;
     // the frame sits at rows / columns 2.. of the bordered conc1 image
     const size_t row_bytes = (size_t)conc_wp(W) * 48;  // row y sits y * row_bytes further
