@@ -89,6 +89,37 @@ __global__ void k_rand(int iters, long long *out, int *sink, unsigned seed)
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[threadIdx.x >> 6] = t1 - t0;
 }
 
+// MFMA stream whose A and B operands change with every instruction (eight fragments each, random contents): the
+// register-file traffic of a real stream, next to the vector stream of another wave.
+__device__ __forceinline__ long long run_rot(int iters, int seed, int *sink)
+{
+    v4i A[8], B[8], acc[8];
+    unsigned h = (threadIdx.x + 1) * 2654435761u ^ (unsigned)seed;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h = h * 1664525u + 1013904223u;
+            A[i][j] = (int)h;
+            h = h * 1664525u + 1013904223u;
+            B[i][j] = (int)h;
+        }
+        acc[i] = v4i{0, 0, 0, 0};
+    }
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i & 7], B[(i + (i >> 3)) & 7], acc[i & 7], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const long long t1 = clock64();
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 0x12345678) *sink = s;
+    return t1 - t0;
+}
+
 // role: 0 idle, 1 MFMA x16, 2 VALU x32, 3 MFMA 8 + VALU 8, 4 MFMA 8 + VALU 16, 5 MFMA 8 + VALU 24, 6 MFMA 8 + VALU 32, 7 VALU x16+MFMA x2
 __global__ void k(int r0, int r1, int r2, int iters, long long *out, int *sink)
 {
@@ -113,6 +144,7 @@ __global__ void k(int r0, int r1, int r2, int iters, long long *out, int *sink)
     case 13: c = run<0, 32, 4>(iters, A, B, threadIdx.x, sink); break;
     case 14: c = run<0, 32, 5>(iters, A, B, threadIdx.x, sink); break;
     case 15: c = run<8, 16, 2>(iters, A, B, threadIdx.x, sink); break;
+    case 16: c = run_rot(iters, threadIdx.x, sink); break;
     default: break;
     }
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[w] = c;
@@ -133,11 +165,12 @@ int main(int argc, char **argv)
         {1, 10, 0, 0}, {1, 11, 0, 0}, {1, 12, 0, 0}, {1, 13, 0, 0}, {1, 14, 0, 0}, {1, 15, 0, 0},
         {2, 1, 10, 0}, {2, 1, 11, 0}, {2, 1, 12, 0}, {2, 1, 13, 0}, {2, 1, 14, 0}, {2, 10, 1, 0}, {2, 11, 1, 0},
         {3, 1, 11, 11}, {3, 1, 1, 11}, {3, 11, 1, 1}, {3, 11, 11, 1}, {3, 2, 1, 1},
+        {1, 16, 0, 0}, {2, 16, 9, 0}, {2, 9, 16, 0}, {2, 16, 11, 0}, {3, 16, 11, 11}, {3, 11, 16, 16}, {3, 16, 16, 11}, {3, 11, 11, 16},
         {3, 1, 2, 2}, {3, 1, 1, 2}, {3, 3, 3, 3}, {3, 4, 4, 4}, {3, 5, 5, 5}, {3, 1, 1, 1}, {3, 2, 2, 2}, {3, 1, 7, 7},
     };
     const char *names[] = {"idle", "M16", "V32", "M8V8", "M8V16", "M8V24", "M8V32", "M2V16", "M16hi", "V64",
-                           "sdwa32", "req32", "perm32", "med32", "pkmax32", "M8req16"};
-    const int nm[] = {0, 16, 0, 8, 8, 8, 8, 2, 16, 0, 0, 0, 0, 0, 0, 8}, nv[] = {0, 0, 32, 8, 16, 24, 32, 16, 0, 64, 32, 32, 32, 32, 32, 16};
+                           "sdwa32", "req32", "perm32", "med32", "pkmax32", "M8req16", "M16rot"};
+    const int nm[] = {0, 16, 0, 8, 8, 8, 8, 2, 16, 0, 0, 0, 0, 0, 0, 8, 16}, nv[] = {0, 0, 32, 8, 16, 24, 32, 16, 0, 64, 32, 32, 32, 32, 32, 16, 0};
     for (auto &cs : cases) {
         const int waves = cs[0];
         for (int rep = 0; rep < 2; ++rep) {
