@@ -159,6 +159,9 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
             unsigned d0, d1, d2;
             quant_row(y, d0, d1, d2);
             unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+#ifdef QCNN_STAMP_ROWS  // diagnostic builds: a stamp behind the requantisation of every row (ahead of its store)
+            C2_STAMP();
+#endif
             if constexpr (CONV == 1) {
                 dst[2] = d2;
                 continue;

@@ -27,7 +27,7 @@ for it in range(20):
     net.synchronize()
     lib.qcnn_debug_stamps(net._h, buf.ctypes.data_as(C.c_void_p))
 print("kernel times (us) k_c1c2, k_c3c4, passes:", net.kernel_times_us())
-PROD, CONS = 3, 8  # stamps per step of a producer / consumer wave
+PROD, CONS = 3, int(os.environ.get("STAMPS_CONS", 8))  # stamps per step of a producer / consumer wave
 for step in (6, 7, 8):
     base = lambda wv: step * PROD if wv < 4 else 2 + (step - 1) * CONS  # (a consumer's step 0 has two stamps only)
     t0 = min(int(buf[wv][base(wv)]) for wv in range(12))
