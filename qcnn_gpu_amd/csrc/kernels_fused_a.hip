@@ -736,7 +736,9 @@ void k_c1c2(const FusedArgs a)
             if (wv < 8) consumer(std::false_type{}, 0, conv_old, all);
             else consumer(std::true_type{}, 0, conv_young, all);
         } else {
-#if C2_DEFER_YOUNGER
+#if C2_DEFER_YOUNGER == 2  // experiment: neither consumer defers (both matrix phases, then both requant phases, side by side)
+            consumer(std::false_type{}, wv < 8 ? 0 : 1, both, part);
+#elif C2_DEFER_YOUNGER
             if (wv < 8) consumer(std::false_type{}, 0, both, part);
             else consumer(std::true_type{}, 1, both, part);
 #else
