@@ -53,7 +53,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-shared-gpus", action="store_true",
                     help="let ranks share a device when fewer than --gpus are present (rehearsal only)")
-    ap.add_argument("--e2e", action="store_true", help="also time the PCIe-inclusive loop of inference/kernel.cu:89-101")
+    ap.add_argument("--e2e", action="store_true", help="(default at N=1; kept for old command lines)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the PCIe-inclusive legs (the timed region of inference/kernel.cu:89-101: 20 blocking frames, "
+                         "then one 256-frame pinned clip through the pipelined entry point)")
     return ap.parse_args()
 
 
@@ -191,6 +194,7 @@ def main():
         step()
     capi.check(lib.qcnn_dev_sync())
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -205,20 +209,41 @@ def main():
     ka_us, kb_us, passes = net.kernel_times_us(reset=True)
     net.set_timing(False)
 
-    # the timed output must be the real thing: the first and the last frame of the batch, whole, against the
-    # oracle on rank 0 (outside the timed region)
+    # the timed output must be the real thing: EVERY frame the timed steps wrote, whole, against the oracle
+    # (outside the timed region; the batch cycles through nsrc distinct frames, so the oracle runs nsrc times
+    # and every output frame is compared with the oracle's result for its source)
     parity = None
     e2e = None
-    if rank == 0:
+    parity_frames = 0
+    if True:
         from oracle import c_oracle
         parity = True
-        rec = np.empty((h, w), np.uint8)
-        for i in sorted({0, B - 1}):
-            capi.check(lib.qcnn_dev_d2h(rec.ctypes.data, C.c_void_p(d_out.value + i * hw), hw))
-            rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i % nsrc]))
-            parity = parity and bool(np.array_equal(rec, rec_o))
-        capi.check(lib.qcnn_dev_d2h(rec.ctypes.data, d_out, hw))
-        if a.e2e:
+        rec_o = [c_oracle.forward_blu(mb, np.ascontiguousarray(anc[k])) for k in range(nsrc)]
+        chunk = max(1, min(B, (256 << 20) // hw))
+        buf = np.empty((chunk, h, w), np.uint8)
+        for i0 in range(0, B, chunk):
+            n = min(chunk, B - i0)
+            capi.check(lib.qcnn_dev_d2h(buf.ctypes.data, C.c_void_p(d_out.value + i0 * hw), n * hw))
+            for j in range(n):
+                parity = parity and bool(np.array_equal(buf[j], rec_o[(i0 + j) % nsrc]))
+            parity_frames += n
+        del buf
+    # what every rank saw, gathered on all ranks: a straggling or doubly used GPU shows in the one line
+    mine = {"rank": rank, "device": dev, "pci_bus_id": capi.pci_bus_id(dev), "host": socket.gethostname(),
+            "mpixels_s": round(a.steps * B * hw / elapsed_local / 1e6, 2), "parity": bool(parity),
+            "k_c1c2_us": round(ka_us, 1), "k_c3c4_us": round(kb_us, 1)}
+    ranks = [mine]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        parity = all(r["parity"] for r in ranks)
+        parity_frames *= world
+        places = [(r["host"], r["pci_bus_id"]) for r in ranks]
+        if ndev.value >= world and len(set(places)) != world:
+            raise SystemExit(f"bench.py: {world} ranks landed on {len(set(places))} distinct device(s): {places}")
+    if rank == 0:
+        rec = rec_o[0]
+        if world == 1 and not a.no_e2e:
             host_in = np.ascontiguousarray(anc[0])
             host_out = np.empty_like(host_in)
             net.bind_io(0, 0)
@@ -245,7 +270,8 @@ def main():
             t1 = time.perf_counter()
             capi.check(lib.qcnn_forward_blu_clip(net._h, p_in, p_out, nclip, hw, None, None, None))
             e2e_clip = nclip * hw / (time.perf_counter() - t1) / 1e6
-            parity = parity and bool(np.array_equal(rec_clip[0], rec)) and bool(np.array_equal(rec_clip[nclip - nsrc], rec))
+            for i in range(nclip):
+                parity = parity and bool(np.array_equal(rec_clip[i], rec_o[i % nsrc]))
             capi.check(lib.qcnn_host_free_pinned(p_in))
             capi.check(lib.qcnn_host_free_pinned(p_out))
 
@@ -301,7 +327,12 @@ def main():
                                             if ka_us + kb_us > 0 else None,
                          "whole_pass_frac_wall": round(2.0 * MACS_PER_PIXEL * value * 1e6 / world / 1e12 / PEAK_INT8_TOPS, 4)},
             "parity_vs_oracle": parity,
+            "parity_frames_checked": parity_frames,
+            "per_rank_mpixels_s": [r["mpixels_s"] for r in ranks],
+            "per_rank_device": [f'{r["host"]}:{r["device"]}:{r["pci_bus_id"]}' for r in ranks],
         }
+        if world > 1:
+            out["per_rank_kernel_us"] = [[r["k_c1c2_us"], r["k_c3c4_us"]] for r in ranks]
         if ndev.value < world:
             out["config"]["note"] = f"{world} ranks share {ndev.value} device(s): a rehearsal, not a scaling measurement"
         if hbm is not None:

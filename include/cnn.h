@@ -32,6 +32,11 @@ public:
     int quantize_out_static(void);                                         /* inference/cnn.cu:189-194 */
     int quantize_out_blu(void);                                            /* inference/cnn.cu:195-200 */
     int viewmem(xwtype *x);                                                /* inference/cnn.cu:203-248 */
+    /* declared by the reference (inference/cnn.cuh:33-34, "free data u and y" / "set u and y") and defined
+     * nowhere in it; here they release / re-allocate u and v of a layer that owns its buffers (build()) and
+     * return QCNN_E_UNSUPPORTED on a layer whose buffers belong to an engine (adopt()) */
+    int freeMem(void);
+    int setMem(void);
     /* adopt buffers owned by a qcnn engine instead of allocating (used by class qvrcnn) */
     int adopt(int batch, int height, int width, int inChannel, int outChannel, int ksize, void *w, void *b, void *u,
               void *v);
@@ -60,6 +65,10 @@ public:
     int build(int batch, int height, int width, int inChannel1, int inChannel2);   /* inference/cnn.cu:268-283 */
     int concat(CovLayer *C1, CovLayer *C2, void *workspace);                        /* inference/cnn.cu:285-320 */
     int concat_fix(CovLayer *C1, CovLayer *C2, convtype max1, convtype max2);       /* inference/cnn.cu:321-353 */
+    /* inference/cnn.cuh:69; its only body (inference/cnn.cu:354-374) is commented out and launches a kernel
+     * the reference does not contain: does the host bookkeeping of that body (step_y, max_u), prints and
+     * returns QCNN_E_UNSUPPORTED */
+    int concat_static(CovLayer *C1, CovLayer *C2);
     int concat_blu(CovLayer *C1, CovLayer *C2);                                     /* inference/cnn.cu:375-394 */
     int adopt(int batch, int height, int width, int inChannel1, int inChannel2, void *conc);
     ~ConcatLayer();
@@ -80,6 +89,7 @@ public:
     int ppro(void);                                                 /* inference/cnn.cu:454-468 */
     int applyRes(xwtype *res);                                      /* inference/cnn.cu:524-529 */
     int applyRes_y(convtype *res, int mul, int shift);              /* inference/cnn.cu:530-535 */
+    int viewmem(xwtype *res);                                       /* inference/cnn.cu:536-549 */
     int adopt(int batch, int channel, int height, int width, void *x, void *x_ppro, void *x_rec);
     ~InputLayer(void);
 

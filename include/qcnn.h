@@ -42,6 +42,10 @@ typedef struct qcnn_engine qcnn_t;
 const char *qcnn_last_error(void);
 const char *qcnn_version(void);
 int qcnn_device_count(int *count);
+/* PCI bus id of device `gpu` as text ("0000:c1:00.0", NUL-terminated, at most len bytes): tells two processes
+ * whether their device numbers mean the same card (the reference reads the device count and ignores it,
+ * inference/kernel.cu:42-43,85-86). */
+int qcnn_device_pci_bus_id(int gpu, char *buf, int len);
 
 /* ---- network level ------------------------------------------------------------------ */
 
@@ -225,7 +229,9 @@ enum {
 };
 int qcnn_tap_bytes(qcnn_t *e, int tap, size_t *bytes);
 int qcnn_tap(qcnn_t *e, int tap, void *host_out, size_t bytes);
-/* Device address of a layered-mode buffer (the public members C*.u / C*.v / Conc*.conc). */
+/* Device address of a layered-mode buffer (the public members C*.u / C*.v / Conc*.conc).  NULL for
+ * QCNN_TAP_FUSED_CONC1: the fused path keeps conc1 as a bordered image in an internal channel order, and the tap
+ * is a converted copy that qcnn_tap makes (of the image the last fused pass wrote, whichever entry point ran it). */
 void *qcnn_tap_device_ptr(qcnn_t *e, int tap);
 
 /* blu, mul, shift of layer l as loaded (CovLayer::blu/mul/shift, inference/cnn.cuh:49-50). */
@@ -340,9 +346,14 @@ int qcnn_dev_h2d(void *dev, const void *host, size_t bytes);
 int qcnn_dev_d2h(void *host, const void *dev, size_t bytes);
 int qcnn_dev_memset(void *dev, int value, size_t bytes);
 int qcnn_dev_sync(void);
+/* Free and total device memory of the current device (hipMemGetInfo); either pointer may be NULL. */
+int qcnn_dev_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* Page-locked host memory, portable: every device of the process may copy from / to it by DMA (the workers of
+ * a multi-GPU run share one clip). */
 int qcnn_host_alloc_pinned(void **host, size_t bytes);
 int qcnn_host_free_pinned(void *host);
-/* Page-locks / releases `bytes` of memory the caller owns (hipHostRegister / hipHostUnregister), e.g. the three
+/* Page-locks (for every device of the process) / releases `bytes` of memory the caller owns (hipHostRegister /
+ * hipHostUnregister), e.g. the three
  * clips of vrcnn_data (inference/yuv_data.cpp:8-10) when they were allocated with new[]. */
 int qcnn_host_register(void *host, size_t bytes);
 int qcnn_host_unregister(void *host);

@@ -47,6 +47,9 @@ public:
     /* the same pass issued call by call through the layer objects, in the order and with the
      * buffers of inference/qvrcnn.cu:168-242 (every u / v / conc is materialised) */
     int forward_blu_layers(void);
+    /* inference/qvrcnn.cuh:33: declared by the reference, defined nowhere in it (inference only); prints
+     * and returns QCNN_E_UNSUPPORTED */
+    int backward(void);
     int save_b_adj(const char *filename);                               /* inference/qvrcnn.cu:288-304 */
     /* The reference's compile-time float32 configuration (FLOAT_CONFIG) as run-time members: load_para of
      * inference/cnn.cu:114-127 (NCHW float model) and forward of inference/qvrcnn.cu:244-285. */

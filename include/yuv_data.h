@@ -36,4 +36,29 @@ public:
     bool pinned; /* the three buffers are page-locked (qcnn_host_alloc_pinned) */
 };
 
+/*
+ * Streaming twin of vrcnn_data::read_data / save_recon_as (inference/yuv_data.cpp:15-42,113-128) for clips that
+ * should not sit in host memory whole: the same files, the same bytes, any range of frames at a time.  Frame i of
+ * a 4:2:0 file starts at byte i * h*w*3/2, so ranges can be read and written by several threads at once (every
+ * call is one positioned read or write per frame; the object keeps no file position).  The recon file is sized
+ * to frames * h*w*3/2 when it is opened: the chroma bytes the reference writes as zeros
+ * (inference/yuv_data.cpp:119-125) are the zeros a file is extended with, only luma is written.
+ * Errors behave like read_data: a message on stdout and exit(1).
+ */
+class vrcnn_stream {
+public:
+    vrcnn_stream(char *orifile, char *inputfile, int frame, int height, int width);
+    /* luma of frames first .. first+count-1 of both files into ori / input (count * h*w bytes each) */
+    void read_frames(int first, int count, datatype *ori, datatype *input) const;
+    void open_recon(char *filename);
+    void write_frames(int first, int count, const datatype *recon) const;
+    ~vrcnn_stream(void);
+
+    int frame, h, w;
+    long nSize; /* frame * h * w, as vrcnn_data::nSize */
+
+private:
+    int ori_fd, input_fd, recon_fd;
+};
+
 #endif

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libqcnn.so")
 
 # every symbol include/qcnn.h declares
 SYMBOLS = (
-    "qcnn_last_error", "qcnn_version", "qcnn_device_count", "qcnn_create", "qcnn_destroy", "qcnn_load_static",
+    "qcnn_last_error", "qcnn_version", "qcnn_device_count", "qcnn_device_pci_bus_id", "qcnn_create", "qcnn_destroy", "qcnn_load_static",
     "qcnn_load_static_mem", "qcnn_upload", "qcnn_upload_async", "qcnn_forward_blu", "qcnn_forward_blu_batch",
     "qcnn_forward_blu_batch_noalloc", "qcnn_forward_blu_layered", "qcnn_batch_group", "qcnn_forward_blu_clip", "qcnn_clip_reserve",
     "qcnn_sync", "qcnn_recon_device_ptr", "qcnn_input_device_ptr", "qcnn_bind_io", "qcnn_download",
@@ -20,7 +20,7 @@ SYMBOLS = (
     "qcnn_layer_params", "qcnn_layer_w_device_ptr", "qcnn_layer_b_device_ptr", "qcnn_set_exact", "qcnn_is_exact",
     "qcnn_stream", "qcnn_set_timing", "qcnn_kernel_times_us", "qcnn_op_ppro", "qcnn_op_conv_static",
     "qcnn_op_quant_blu", "qcnn_op_apply_res_y", "qcnn_set_device", "qcnn_dev_alloc", "qcnn_dev_free", "qcnn_dev_h2d",
-    "qcnn_dev_d2h", "qcnn_dev_memset", "qcnn_dev_sync", "qcnn_host_alloc_pinned", "qcnn_host_free_pinned",
+    "qcnn_dev_d2h", "qcnn_dev_memset", "qcnn_dev_sync", "qcnn_dev_mem_info", "qcnn_host_alloc_pinned", "qcnn_host_free_pinned",
     "qcnn_host_register", "qcnn_host_unregister",
     "qcnn_hwcn2nchw_vect_c", "qcnn_model_qfp_hwcn2nchw_vect_c",
     # dynamic-quantisation path
@@ -66,6 +66,7 @@ def load():
     L.qcnn_last_error.restype = C.c_char_p
     L.qcnn_version.restype = C.c_char_p
     L.qcnn_device_count.argtypes = [C.POINTER(i)]
+    L.qcnn_device_pci_bus_id.argtypes = [i, C.c_char_p, i]
     L.qcnn_create.argtypes = [i, i, i, i, i, C.POINTER(vp)]
     L.qcnn_destroy.argtypes = [vp]
     L.qcnn_load_static.argtypes = [vp, C.c_char_p]
@@ -113,6 +114,7 @@ def load():
     L.qcnn_dev_h2d.argtypes = [vp, vp, sz]
     L.qcnn_dev_d2h.argtypes = [vp, vp, sz]
     L.qcnn_dev_memset.argtypes = [vp, i, sz]
+    L.qcnn_dev_mem_info.argtypes = [C.POINTER(sz), C.POINTER(sz)]
     L.qcnn_host_alloc_pinned.argtypes = [C.POINTER(vp), sz]
     L.qcnn_host_free_pinned.argtypes = [vp]
     L.qcnn_host_register.argtypes = [vp, sz]
@@ -156,3 +158,10 @@ def check(rc: int) -> int:
     if rc < 0:
         raise QcnnError(rc, load().qcnn_last_error().decode(errors="replace"))
     return rc
+
+
+def pci_bus_id(gpu: int) -> str:
+    """PCI bus id of device `gpu` (qcnn_device_pci_bus_id)."""
+    buf = C.create_string_buffer(64)
+    check(load().qcnn_device_pci_bus_id(int(gpu), buf, 64))
+    return buf.value.decode()

@@ -26,10 +26,15 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// (a failed call is reported once: the runtime's own record of it is cleared, or the next kernel launcher, which asks
+// hipGetLastError() whether its launch went through, would report this failure as its own)
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(QCNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return fail(QCNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                \
+        }                                                                                          \
     } while (0)
 
 // Layer table of qvrcnn::qvrcnn (inference/qvrcnn.cu:11-18).
@@ -92,7 +97,8 @@ struct qcnn_engine {
     const uint8_t *bound_y = nullptr;
     uint8_t *bound_rec = nullptr;
     // fused path
-    int8_t *conc1_int = nullptr;  // [conc_frames][H][W][48]
+    int8_t *conc1_int = nullptr;  // [conc_frames] bordered images of conc_bytes(H, W)
+    const int8_t *last_conc = nullptr;  // the image the last fused pass wrote frame 0 of its last launch into (QCNN_TAP_FUSED_CONC1)
     int8_t *scratch_ptr = nullptr;  // this GPU's copy of the static scratch (qcnn_forward_blu_batch_noalloc), or null
     hipError_t scratch_err = hipSuccess;
     int conc_frames = 0;          // capacity of conc1_int, in frames
@@ -480,20 +486,27 @@ static int load_dyn_image(qcnn_engine *e, const uint8_t *img, size_t bytes)
     return QCNN_OK;
 }
 
-// conc1 scratch for `frames` frames per launch (grown on demand, never shrunk)
+// conc1 scratch for `frames` frames per launch (grown on demand, never shrunk).  The larger image is allocated
+// before the old one is released, so a failed allocation leaves the engine as it was (still good for launches of
+// conc_frames frames).
 static int ensure_conc(qcnn_engine *e, int frames)
 {
-    if (frames <= e->conc_frames) return QCNN_OK;
+    if (frames <= e->conc_frames && e->conc1_int) return QCNN_OK;
     HIP_TRY(hipSetDevice(e->gpu));
-    if (e->stream) HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->conc1_int) HIP_TRY(hipFree(e->conc1_int));
-    e->conc1_int = nullptr;
-    e->conc_frames = 0;
     const size_t bytes = (size_t)frames * conc_bytes(e->H, e->W);
-    HIP_TRY(hipMalloc(&e->conc1_int, bytes));
+    int8_t *grown = nullptr;
+    HIP_TRY(hipMalloc(&grown, bytes));
     // the border stays zero: kernel A writes the frame only (cleared on the engine stream, which does not wait
     // for the null stream)
-    HIP_TRY(hipMemsetAsync(e->conc1_int, 0, bytes, e->stream));
+    hipError_t he = hipMemsetAsync(grown, 0, bytes, e->stream);
+    if (he == hipSuccess && e->stream) he = hipStreamSynchronize(e->stream);  // also: nothing reads the old image any more
+    if (he != hipSuccess) {
+        (void)hipFree(grown);
+        return fail(QCNN_E_HIP, "clearing the conc1 image failed: %s", hipGetErrorString(he));
+    }
+    if (e->conc1_int) (void)hipFree(e->conc1_int);
+    if (e->last_conc == e->conc1_int) e->last_conc = nullptr;  // what the tap would convert is gone
+    e->conc1_int = grown;
     e->conc_frames = frames;
     return QCNN_OK;
 }
@@ -536,6 +549,13 @@ int qcnn_device_count(int *count)
 {
     if (!count) return fail(QCNN_E_ARG, "count is null");
     HIP_TRY(hipGetDeviceCount(count));
+    return QCNN_OK;
+}
+
+int qcnn_device_pci_bus_id(int gpu, char *buf, int len)
+{
+    if (!buf || len < 2) return fail(QCNN_E_ARG, "bad buffer");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, gpu));
     return QCNN_OK;
 }
 
@@ -721,7 +741,11 @@ static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nfr
                          bool timed = true)
 {
     HIP_TRY(hipSetDevice(e->gpu));
-    const FusedArgs a = fused_args(e, y, rec, nframes, stride, conc1 ? conc1 : e->conc1_int);
+    if (!conc1) conc1 = e->conc1_int;
+    if (!conc1 || (conc1 == e->conc1_int && nframes > e->conc_frames))
+        return fail(QCNN_E_STATE, "no conc1 image for a launch of %d frame(s) (an earlier allocation failed)", nframes);
+    const FusedArgs a = fused_args(e, y, rec, nframes, stride, conc1);
+    e->last_conc = conc1;
     hipEvent_t *ev = nullptr;
     if (e->timing && timed) {
         if (e->ev_used + 3 > e->ev.size()) {
@@ -1227,7 +1251,7 @@ static int tap_info(qcnn_t *e, int tap, void **dev, size_t *bytes)
     case QCNN_TAP_CONC1: *dev = e->conc1; *bytes = 48 * HW; return 0;
     case QCNN_TAP_CONC2: *dev = e->conc2; *bytes = 48 * HW; return 0;
     case QCNN_TAP_X_REC: *dev = e->bound_rec ? e->bound_rec : e->x_rec; *bytes = HW; return 0;
-    case QCNN_TAP_FUSED_CONC1: *dev = e->conc1_int; *bytes = 48 * HW; return 0;  // size of the reference-layout copy
+    case QCNN_TAP_FUSED_CONC1: *dev = nullptr; *bytes = 48 * HW; return 0;  // a converted copy: no device address of its own
     case QCNN_TAP_V_C4: *dev = e->v4; *bytes = HW; return 0;
     case QCNN_TAP_F_X_PPRO: *dev = e->f_xp; *bytes = sizeof(float) * HW; return 0;
     case QCNN_TAP_F_U_C1: *dev = e->f_u1; *bytes = sizeof(float) * 64 * HW; return 0;
@@ -1273,9 +1297,12 @@ int qcnn_tap(qcnn_t *e, int tap, void *host_out, size_t bytes)
     if (bytes < need) return fail(QCNN_E_ARG, "tap %d needs %zu bytes, buffer has %zu", tap, need, bytes);
     if (tap == QCNN_TAP_FUSED_CONC1) {
         // convert the fused path's [H][W][48] image to the layout of Conc1.conc in a scratch buffer
+        // (of whichever image the last fused pass wrote: the engine's own, or the static scratch of the entry
+        // point that allocates nothing)
+        if (!e->last_conc) return fail(QCNN_E_STATE, "no fused forward pass has run on this engine");
         int8_t *tmp = nullptr;
         HIP_TRY(hipMalloc(&tmp, need));
-        hipError_t he = launch_conc_to_ref(e->conc1_int, tmp, e->H, e->W, e->stream);
+        hipError_t he = launch_conc_to_ref(e->last_conc, tmp, e->H, e->W, e->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(host_out, tmp, need, hipMemcpyDeviceToHost, e->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
         (void)hipFree(tmp);
@@ -1548,10 +1575,20 @@ int qcnn_dev_sync(void)
     HIP_TRY(hipDeviceSynchronize());
     return QCNN_OK;
 }
+int qcnn_dev_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return QCNN_OK;
+}
 int qcnn_host_alloc_pinned(void **host, size_t bytes)
 {
     if (!host) return fail(QCNN_E_ARG, "null argument");
-    HIP_TRY(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault));
+    // portable: page-locked for every device of the process, not only the current one (the workers of a
+    // multi-GPU run all copy out of one clip)
+    HIP_TRY(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocPortable));
     return QCNN_OK;
 }
 int qcnn_host_free_pinned(void *host)
@@ -1562,6 +1599,9 @@ int qcnn_host_free_pinned(void *host)
 int qcnn_host_register(void *host, size_t bytes)
 {
     if (!host) return fail(QCNN_E_ARG, "null argument");
+    // portable (every device of the process may copy from it by DMA) where the runtime takes the flag
+    if (hipHostRegister(host, bytes, hipHostRegisterPortable) == hipSuccess) return QCNN_OK;
+    (void)hipGetLastError();
     HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
     return QCNN_OK;
 }

@@ -144,6 +144,25 @@ int CovLayer::viewmem(xwtype *x)
     return 0;
 }
 
+// "free data u and y" / "set u and y" (inference/cnn.cuh:33-34; no body in the reference)
+int CovLayer::freeMem(void)
+{
+    if (!owns_) return unsupported("CovLayer::freeMem on buffers owned by an engine");
+    check(qcnn_dev_sync());
+    if (u) check(qcnn_dev_free(u));
+    if (v) check(qcnn_dev_free(v));
+    u = v = nullptr;
+    return 0;
+}
+
+int CovLayer::setMem(void)
+{
+    if (!owns_) return unsupported("CovLayer::setMem on buffers owned by an engine");
+    if (!u) check(qcnn_dev_alloc(&u, sizeof(convtype) * (size_t)uSize));
+    if (!v) check(qcnn_dev_alloc(&v, sizeof(xwtype) * (size_t)vSize));
+    return 0;
+}
+
 int CovLayer::load_para(FILE *fp)
 {
     read_layer_block(this, fp, &step_w, nullptr, 0, owns_);
@@ -248,6 +267,18 @@ int ConcatLayer::concat_blu(CovLayer *C1, CovLayer *C2)
     return 0;
 }
 
+int ConcatLayer::concat_static(CovLayer *C1, CovLayer *C2)
+{
+    // the host half of the commented-out body (inference/cnn.cu:357-361); its device half launches
+    // CHW2CHW_VECT_C_QUANT, which exists nowhere in the reference
+    for (CovLayer *L : {C1, C2}) {
+        if (L->mul <= 0) return unsupported("ConcatLayer::concat_static without mul / shift");
+        L->step_y = ((1 << L->shift) + L->mul / 2) / L->mul;
+        L->max_u = 127 * L->step_y;
+    }
+    return unsupported("ConcatLayer::concat_static (no body in the reference; concat_blu is the static concat)");
+}
+
 int ConcatLayer::concat(CovLayer *C1, CovLayer *C2, void *workspace)
 {
     convtype max1, max2;
@@ -340,6 +371,20 @@ int InputLayer::applyRes_y(convtype *res, int mul, int shift)
 int InputLayer::applyRes(xwtype *res)
 {
     check(qcnn_op_apply_res(x, res, x_rec, (size_t)inSize, nullptr));
+    return 0;
+}
+
+int InputLayer::viewmem(xwtype *res)
+{
+    // inference/cnn.cu:536-549 copies res, x and x_rec to the host and drops them again (a debugger hook:
+    // nothing is printed); the copies are kept, so a bad pointer fails here as it does there
+    const size_t n = (size_t)height * width * inChannel * batch;
+    std::vector<xwtype> res_h(n);
+    std::vector<datatype> x_h(n), rec_h(n);
+    check(qcnn_dev_sync());
+    check(qcnn_dev_d2h(res_h.data(), res, sizeof(xwtype) * n));
+    check(qcnn_dev_d2h(x_h.data(), x, sizeof(datatype) * n));
+    check(qcnn_dev_d2h(rec_h.data(), x_rec, sizeof(datatype) * n));
     return 0;
 }
 

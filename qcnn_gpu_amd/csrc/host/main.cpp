@@ -15,11 +15,22 @@
 //   QCNN_PIPELINE=1    run the timed region through qcnn_forward_blu_clip: the same H2D / forward_blu /
 //                      D2H per frame, as a three-stream pipeline over groups of frames, and the PSNR
 //                      sums on the device
+//   QCNN_STREAM=1      the pipelined frame loop on a clip that never sits in host memory whole: reader threads
+//                      (QCNN_STREAM_READERS, default 4) fill chunks of QCNN_STREAM_CHUNK frames (default: the
+//                      engine's frames per launch) by positioned reads, one worker per GPU runs
+//                      qcnn_forward_blu_clip on whole chunks, writer threads (QCNN_STREAM_WRITERS, default 2) write
+//                      the reconstruction, all at once; host buffers = (GPUs + readers + writers) chunks x 3.
+//                      The time reported then INCLUDES reading and writing the files (the reference reads the
+//                      whole clip before its clock starts); a breakdown goes to stderr.
+//   QCNN_REPORT_RSS=1  print the peak resident set of the run on stderr when it ends
 //   QCNN_PSNR_PF=1     also print "PSNR of Frame %d:%f" per frame (inference/yuv_data.cpp:109)
 //   QCNN_SAVE_RECON=f  write the reconstruction as YUV 4:2:0 (inference/yuv_data.cpp:113-128)
 //   QCNN_CONVERT=1     run convert_model() instead (inference/kernel.cu:17-26): HWCN -> NCHW_VECT_C,
 //                      input pattern QCNN_MODEL_HWCN (default "qvrcnn_hwcn_8bit_qfp_%d.data")
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <cstdint>
@@ -29,6 +40,22 @@
 
 #include "qvrcnn.h"
 #include "yuv_data.h"
+
+// Peak resident set of this process image in MB: VmHWM of /proc/self/status (getrusage's ru_maxrss is carried over
+// from the process that started this one, so it says nothing when the parent was large).
+static double peak_rss_mb(void)
+{
+    double mb = 0;
+    if (FILE *f = fopen("/proc/self/status", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            long kb;
+            if (sscanf(line, "VmHWM: %ld kB", &kb) == 1) mb = kb / 1024.0;
+        }
+        fclose(f);
+    }
+    return mb;
+}
 
 static const char *env_or(const char *name, const char *dflt)
 {
@@ -100,7 +127,9 @@ static void worker_clip(int gpu, int ngpu, qvrcnn *net, vrcnn_data *d, int frame
     }
 }
 
-// stdout line, log.txt record and recon_psnr.data double of inference/kernel.cu:105-115
+static void emit_record(char *input_fn, int frame, int height, int width, double psnr1, double psnr2, long long us);
+
+// PSNR of inference/kernel.cu:105-106 (per frame too when asked), then the record
 static void report(vrcnn_data &d, char *input_fn, int frame, int height, int width, long long us,
                    const std::vector<uint64_t> *sse_before = nullptr, const std::vector<uint64_t> *sse_after = nullptr,
                    bool chroma = false)
@@ -113,7 +142,6 @@ static void report(vrcnn_data &d, char *input_fn, int frame, int height, int wid
         if (getenv("QCNN_SAVE_RECON")) d.patch_chroma_into(getenv("QCNN_SAVE_RECON"));
         return;
     }
-    time_t now = time(0);
     double psnr1, psnr2;
     if (sse_before && sse_after) {
         // the integer sums came from the device; the same doubles as vrcnn_data::psnr / psnr_pf
@@ -131,6 +159,14 @@ static void report(vrcnn_data &d, char *input_fn, int frame, int height, int wid
         psnr1 = d.psnr(d.input);
         psnr2 = d.psnr(d.recon);
     }
+    emit_record(input_fn, frame, height, width, psnr1, psnr2, us);
+    if (getenv("QCNN_SAVE_RECON")) d.save_recon_as(getenv("QCNN_SAVE_RECON"));
+}
+
+// stdout line, log.txt record and recon_psnr.data double of inference/kernel.cu:107-115
+static void emit_record(char *input_fn, int frame, int height, int width, double psnr1, double psnr2, long long us)
+{
+    time_t now = time(0);
     printf("\nbefore net:PSNR=%.3f\nafter quantized net:PSNR=%.3f\ntime:%lldus\n", psnr1, psnr2, us);
     FILE *logfile = fopen("log.txt", "a+");
     if (!logfile)
@@ -149,13 +185,147 @@ static void report(vrcnn_data &d, char *input_fn, int frame, int height, int wid
         fwrite(&psnr2, sizeof(double), 1, logfile);
         fclose(logfile);
     }
-    if (getenv("QCNN_SAVE_RECON")) d.save_recon_as(getenv("QCNN_SAVE_RECON"));
+}
+
+// QCNN_STREAM=1: the timed frame loop of inference/kernel.cu:89-101 as a pipeline over CHUNKS of a clip that is
+// read, processed and written at the same time, so that host memory holds a few chunks instead of the clip
+// (vrcnn_data holds frame*h*w bytes three times: 3.1 GB for 500 frames of 1920x1080):
+//   readers   chunk c is read by reader c mod R with positioned reads (vrcnn_stream::read_frames) into slot c mod S
+//   workers   one per GPU; each takes the next chunk in order as soon as it is ready and runs it through
+//             qcnn_forward_blu_clip (H2D / fused kernels / D2H overlapped on three streams, integer SSE against
+//             the original on the device): whole chunks per GPU, whichever GPU is free first
+//   writers   chunk c is written by writer c mod W (reconstruction luma at its file offset), which frees the slot
+// A slot is reused once its previous chunk has been written: S = GPUs + readers + writers slots of three pinned
+// buffers.  The per-frame sums stay in two small arrays, so the PSNR lines are printed in frame order at the end,
+// where the whole-clip path prints them.
+static void testqvrcnn_stream(char *ori_fn, char *input_fn, char *model_fn, int frame, int channel, int height, int width,
+                              int ngpu)
+{
+    using clk = std::chrono::steady_clock;
+    const size_t fs = (size_t)channel * height * width;
+    if (ngpu < 1) ngpu = 1;
+    std::vector<qvrcnn *> nets;
+    for (int g = 0; g < ngpu; ++g) {
+        nets.push_back(new qvrcnn(device_of(g), 1, channel, height, width));
+        nets.back()->load_static_para(model_fn);
+    }
+    int chunk = atoi(env_or("QCNN_STREAM_CHUNK", "0"));
+    if (chunk < 1) check(qcnn_batch_group(nets[0]->engine, 0, &chunk));
+    if (chunk > frame) chunk = frame;
+    const int nchunks = (frame + chunk - 1) / chunk;
+    auto threads_of = [&](const char *name, const char *dflt) {
+        const int n = atoi(env_or(name, dflt));
+        return n < 1 ? 1 : n > 16 ? 16 : n > nchunks ? nchunks : n;
+    };
+    const int R = threads_of("QCNN_STREAM_READERS", "4"), W = threads_of("QCNN_STREAM_WRITERS", "2");
+    const int S = ngpu + R + W < nchunks ? ngpu + R + W : nchunks;
+    for (int g = 0; g < ngpu; ++g) check(qcnn_clip_reserve(nets[g]->engine, chunk, 1));
+    // slots: page-locked when the runtime grants it, ordinary memory otherwise
+    std::vector<datatype *> buf(3 * (size_t)S, nullptr);
+    bool pinned = true;
+    for (size_t i = 0; i < buf.size() && pinned; ++i) {
+        void *p = nullptr;
+        pinned = qcnn_host_alloc_pinned(&p, (size_t)chunk * fs) == 0;
+        buf[i] = static_cast<datatype *>(p);
+    }
+    if (!pinned)
+        for (size_t i = 0; i < buf.size(); ++i) {
+            if (buf[i]) qcnn_host_free_pinned(buf[i]);
+            buf[i] = new datatype[(size_t)chunk * fs];
+        }
+    auto slot_ori = [&](int c) { return buf[3 * (size_t)(c % S)]; };
+    auto slot_in = [&](int c) { return buf[3 * (size_t)(c % S) + 1]; };
+    auto slot_rec = [&](int c) { return buf[3 * (size_t)(c % S) + 2]; };
+    auto first_of = [&](int c) { return c * chunk; };
+    auto count_of = [&](int c) { return frame - c * chunk < chunk ? frame - c * chunk : chunk; };
+
+    vrcnn_stream io(ori_fn, input_fn, frame, height, width);
+    if (getenv("QCNN_SAVE_RECON")) io.open_recon(getenv("QCNN_SAVE_RECON"));
+    std::vector<uint64_t> sse_before(frame), sse_after(frame);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> ready(nchunks, 0), computed(nchunks, 0), written(nchunks, 0);
+    std::atomic<int> next_chunk{0};
+    std::atomic<long long> read_us{0}, gpu_us{0}, write_us{0};
+    auto us_since = [](clk::time_point t0) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count(); };
+    auto wait_for = [&](std::vector<char> &flags, int c) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return flags[c] != 0; });
+    };
+    auto raise = [&](std::vector<char> &flags, int c) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            flags[c] = 1;
+        }
+        cv.notify_all();
+    };
+
+    const auto t1 = clk::now();
+    std::vector<std::thread> th;
+    for (int r = 0; r < R; ++r)
+        th.emplace_back([&, r] {
+            for (int c = r; c < nchunks; c += R) {
+                if (c >= S) wait_for(written, c - S);  // the slot's previous chunk has left it
+                const auto t0 = clk::now();
+                io.read_frames(first_of(c), count_of(c), slot_ori(c), slot_in(c));
+                read_us += us_since(t0);
+                raise(ready, c);
+            }
+        });
+    for (int g = 0; g < ngpu; ++g)
+        th.emplace_back([&, g] {
+            check(qcnn_set_device(device_of(g)));  // the current device is a per-thread setting
+            for (;;) {
+                const int c = next_chunk++;
+                if (c >= nchunks) break;
+                wait_for(ready, c);
+                const auto t0 = clk::now();
+                check(qcnn_forward_blu_clip(nets[g]->engine, slot_in(c), slot_rec(c), count_of(c), fs, slot_ori(c),
+                                            sse_before.data() + first_of(c), sse_after.data() + first_of(c)));
+                gpu_us += us_since(t0);
+                raise(computed, c);
+            }
+        });
+    for (int k = 0; k < W; ++k)
+        th.emplace_back([&, k] {
+            for (int c = k; c < nchunks; c += W) {
+                wait_for(computed, c);
+                const auto t0 = clk::now();
+                io.write_frames(first_of(c), count_of(c), slot_rec(c));
+                write_us += us_since(t0);
+                raise(written, c);
+            }
+        });
+    for (auto &t : th) t.join();
+    const long long us = us_since(t1);
+
+    const long hw = (long)height * width;
+    unsigned long long tb = 0, ta = 0;
+    for (int i = 0; i < frame; ++i) {
+        if (getenv("QCNN_PSNR_PF")) printf("PSNR of Frame %d:%f\n", i, vrcnn_data::psnr_from_sse(sse_after[i], hw));  // inference/yuv_data.cpp:109
+        tb += sse_before[i], ta += sse_after[i];
+    }
+    emit_record(input_fn, frame, height, width, vrcnn_data::psnr_from_sse(tb, io.nSize), vrcnn_data::psnr_from_sse(ta, io.nSize), us);
+    fprintf(stderr,
+            "stream: %d frames in %d chunks of %d, %d slot(s) x 3 buffers = %.1f MB of %s host memory, %d reader(s), %d GPU worker(s), "
+            "%d writer(s); busy: read %.1f ms, gpu %.1f ms, write %.1f ms; wall %.1f ms (file time included); max RSS %.1f MB\n",
+            frame, nchunks, chunk, S, 3.0 * S * chunk * fs / 1e6, pinned ? "page-locked" : "pageable", R, ngpu, W, read_us / 1e3,
+            gpu_us / 1e3, write_us / 1e3, us / 1e3, peak_rss_mb());
+    for (datatype *p : buf) {
+        if (pinned) qcnn_host_free_pinned(p);
+        else delete[] p;
+    }
+    for (qvrcnn *n : nets) delete n;
 }
 
 // chroma = true: the same loop over the U and V planes (half size, two per frame) of the two files
 static void testqvrcnn(char *ori_fn, char *input_fn, char *model_fn, int frame, int channel, int height, int width,
                        int ngpu, bool chroma = false)
 {
+    if (getenv("QCNN_STREAM") && !dynamic_mode() && !float_mode() && !chroma) {
+        testqvrcnn_stream(ori_fn, input_fn, model_fn, frame, channel, height, width, ngpu);
+        return;
+    }
     vrcnn_data test_data(frame, height, width);
     auto read = [&]() {
         if (chroma) test_data.read_chroma(ori_fn, input_fn);
@@ -254,6 +424,9 @@ static int run_all(char *oriname, char *inputname, int height, int width)
             testqvrcnn(oriname, input_fn, model_fn, 2 * (frames > 0 ? frames : 1), CHANNEL, height / 2, width / 2, ngpu, true);
             check(qcnn_dev_sync());
         }
+    }
+    if (getenv("QCNN_REPORT_RSS")) {  // peak resident set of the whole run, on stderr
+        fprintf(stderr, "max RSS %.1f MB\n", peak_rss_mb());
     }
     return 0;
 }

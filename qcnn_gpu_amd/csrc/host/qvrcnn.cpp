@@ -171,6 +171,12 @@ int qvrcnn::forward_layers(void)
     return 0;
 }
 
+int qvrcnn::backward(void)
+{
+    printf("qvrcnn::backward: not available (declared in inference/qvrcnn.cuh:33, defined nowhere)\n");
+    return QCNN_E_UNSUPPORTED;
+}
+
 int qvrcnn::save_b_adj(const char *filename)
 {
     // inference/qvrcnn.cu:288-304 appends the six b_adj arrays; they live in device memory, so they are

@@ -1,6 +1,10 @@
 // vrcnn_data of the reference (inference/yuv_data.cpp): YUV 4:2:0 luma reader, PSNR, recon writer.
 #include "yuv_data.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 vrcnn_data::vrcnn_data(int frame, int height, int width)
 {
     this->frame = frame;
@@ -194,4 +198,82 @@ double vrcnn_data::psnr_from_sse(unsigned long long sse, long n)
     double mse = (double)sse;
     mse /= (double)n;
     return 10 * log10(65025.0 / mse);
+}
+
+// ---------------------------------------------------------------------------------------------
+// vrcnn_stream: positioned reads / writes of frame ranges (see include/yuv_data.h)
+vrcnn_stream::vrcnn_stream(char *orifile, char *inputfile, int frame_, int height, int width)
+    : frame(frame_), h(height), w(width), nSize((long)frame_ * height * width), ori_fd(-1), input_fd(-1), recon_fd(-1)
+{
+    ori_fd = open(orifile, O_RDONLY);
+    if (ori_fd < 0) {
+        printf("%s\n", orifile);
+        printf("open ori file failed\n");  // inference/yuv_data.cpp:19-23
+        exit(1);
+    }
+    input_fd = open(inputfile, O_RDONLY);
+    if (input_fd < 0) {
+        printf("%s\n", inputfile);
+        printf("open input file failed\n");  // inference/yuv_data.cpp:25-31
+        exit(1);
+    }
+}
+
+static void read_fully(int fd, datatype *dst, size_t n, off_t at, int frame_no)
+{
+    while (n > 0) {
+        const ssize_t got = pread(fd, dst, n, at);
+        if (got <= 0) {
+            printf("short read at frame %d\n", frame_no);
+            exit(1);
+        }
+        dst += got, at += got, n -= (size_t)got;
+    }
+}
+
+void vrcnn_stream::read_frames(int first, int count, datatype *ori, datatype *input) const
+{
+    const size_t hw = (size_t)h * w;
+    for (int i = 0; i < count; ++i) {
+        // luma only; the h*w/2 chroma bytes behind it are skipped (inference/yuv_data.cpp:34-37)
+        const off_t at = (off_t)(first + i) * (off_t)(hw + hw / 2);
+        read_fully(ori_fd, ori + i * hw, hw, at, first + i);
+        read_fully(input_fd, input + i * hw, hw, at, first + i);
+    }
+}
+
+void vrcnn_stream::open_recon(char *filename)
+{
+    recon_fd = open(filename, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const size_t hw = (size_t)h * w;
+    if (recon_fd < 0 || ftruncate(recon_fd, (off_t)frame * (off_t)(hw + hw / 2)) != 0) {
+        printf("write file failed\n");  // inference/yuv_data.cpp:116
+        exit(1);
+    }
+}
+
+void vrcnn_stream::write_frames(int first, int count, const datatype *recon) const
+{
+    if (recon_fd < 0) return;
+    const size_t hw = (size_t)h * w;
+    for (int i = 0; i < count; ++i) {
+        const datatype *src = recon + i * hw;
+        off_t at = (off_t)(first + i) * (off_t)(hw + hw / 2);
+        size_t n = hw;
+        while (n > 0) {
+            const ssize_t put = pwrite(recon_fd, src, n, at);
+            if (put <= 0) {
+                printf("write file failed\n");
+                exit(1);
+            }
+            src += put, at += put, n -= (size_t)put;
+        }
+    }
+}
+
+vrcnn_stream::~vrcnn_stream(void)
+{
+    if (ori_fd >= 0) close(ori_fd);
+    if (input_fd >= 0) close(input_fd);
+    if (recon_fd >= 0) close(recon_fd);
 }

@@ -193,6 +193,12 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         const unsigned lds_c = ring_s + grp * GROUP_BYTES + j * ROW_BYTES + share, lds_y = yring_s + (ygrp * R + j) * YSLOT;
         const int off_c = crow * row_bytes + xw * 48 + share, off_y = yrow * W + x0;
         unsigned long long saved;
+        // (m0 is written twice and is listed as clobbered, so the compiler keeps nothing of its own in it across the
+        // block; between an s_mov to m0 and the LDS-direct load that reads it sits one other instruction, the wait
+        // state this hazard needs.  The compiler calls m0 a reserved register and warns about seeing it in a clobber
+        // list; the clobber still becomes an implicit definition of m0 on the statement, which is the point.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
         asm volatile("s_mov_b64 %0, exec\n\t"
                      "s_mov_b32 m0, %1\n\t"
                      "s_mov_b64 exec, %2\n\t"
@@ -204,7 +210,8 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
                      : "=&s"(saved)
                      : "s"(lds_c), "s"(row_lanes), "v"(lane16), "s"(conc_rsrc), "s"(off_c), "s"(lds_y), "v"(y_voff), "s"(y_rsrc),
                        "s"(off_y)
-                     : "memory");
+                     : "memory", "m0");
+#pragma clang diagnostic pop
     };
     // the lane's read addresses: B fragments of a conc1 row (+ group * GROUP_BYTES + row * 864 + s * 48), the Y
     // pixel of its column (+ slot * YSLOT)
@@ -411,7 +418,7 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // frame / the bordered image, so that the fast loop clamps nothing.
     int t_lo = T, t_hi = T;
     if (!edge_strip) {
-        int last = (H - 3 - ya < yb - 1 - ya ? H - 3 - ya : yb - 1 - ya);  // R t may be at most this
+        int last = (H + 3 - R - ya < yb + 5 - R - ya ? H + 3 - R - ya : yb + 5 - R - ya);  // R t may be at most this: ya - 3 + R t + R - 1 <= H - 1 and ya - 5 + R t + R - 1 <= yb - 1
         last = last < H + 5 - 3 * R - ya ? last : H + 5 - 3 * R - ya;      // ya - 5 + R t + 3 R - 1 <= H - 1
         last = last < H + 4 - 3 * R - ya ? last : H + 4 - 3 * R - ya;      // ya + (t + 3) R - 1 <= H + 3
         t_lo = ya >= 3 ? 1 : (3 - ya + R - 1) / R > 1 ? (3 - ya + R - 1) / R : 1;

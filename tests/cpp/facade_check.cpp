@@ -62,6 +62,19 @@ int main(int argc, char **argv)
     C1.quantize_out_blu();
     dump(out + ".c1v", C1.v, (size_t)64 * H * W);
     if (getenv("FACADE_VIEWMEM")) C1.viewmem((xwtype *)I1.x_ppro);
+    {
+        // members the reference declares and never (or only in a comment) defines: inference/cnn.cuh:33-34,69,89,
+        // inference/qvrcnn.cuh:33
+        const int fm = C1.freeMem(), fu = C1.u == nullptr && C1.v == nullptr;
+        const int sm = C1.setMem(), su = C1.u != nullptr && C1.v != nullptr;
+        C1.quantize_out_blu();  // the buffers are usable again (u holds garbage now, the call must not fault)
+        ConcatLayer cc;
+        const int cs = cc.concat_static(&net.C2_1, &net.C2_2);
+        const int vm = I1.viewmem((xwtype *)I1.x_rec);
+        printf("declared-only members: freeMem %d (%d) setMem %d (%d) adopted freeMem %d concat_static %d step_y %d viewmem %d "
+               "backward %d\n",
+               fm, fu, sm, su, net.C1.freeMem(), cs, net.C2_1.step_y, vm, net.backward());
+    }
 
     if (argc > 7) {
         char *dmodel = argv[7];

@@ -147,6 +147,12 @@ def test_cpp_layer_api_matches_oracle(tmp_path):
     t = synth.QUANT_TRIPLES[qp]
     assert f"C1 blu={t[0][0]} mul={t[0][1]} shift={t[0][2]}  C4 mul={t[5][1]} shift={t[5][2]}" in r.stdout
     assert "mul:%d,shift:%d" % (t[0][1], t[0][2]) in r.stdout      # viewmem dump, inference/cnn.cu:235
+    # members the reference declares without a body (inference/cnn.cuh:33-34,69, qvrcnn.cuh:33) and InputLayer::viewmem
+    # (inference/cnn.cu:536-549): freeMem / setMem release and restore u and v of an owning layer and refuse on an
+    # adopted one, concat_static does its host bookkeeping and reports unsupported (-6), viewmem is silent
+    step_y = ((1 << t[1][2]) + t[1][1] // 2) // t[1][1]
+    assert ("declared-only members: freeMem 0 (1) setMem 0 (1) adopted freeMem -6 concat_static -6 step_y %d viewmem 0 "
+            "backward -6" % step_y) in r.stdout
 
 
 def test_cpp_dynamic_layer_api_matches_oracle(tmp_path):
