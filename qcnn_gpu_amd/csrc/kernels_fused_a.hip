@@ -135,6 +135,12 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
     constexpr bool EXACT = MODE == A_FLOAT;
     static_assert(CONV == 3 || MODE == A_INT, "single-convolution waves exist on the integer path only");
     auto quant_row = [&](int y, unsigned &d0, unsigned &d1, unsigned &d2) {
+#ifdef QCNN_ABL_NOREQ2  // diagnostic builds only (garbage results): the consumers' requantisation switched off
+        d0 = acc.a21[0][y][0] ^ acc.a21[0][y][1] ^ acc.a21[0][y][2] ^ acc.a21[0][y][3];
+        d1 = acc.a21[1][y][0] ^ acc.a21[1][y][1] ^ acc.a21[1][y][2] ^ acc.a21[1][y][3];
+        d2 = acc.a22[y][0] ^ acc.a22[y][1] ^ acc.a22[y][2] ^ acc.a22[y][3];
+        return;
+#endif
         if constexpr (MODE == A_INT && CONV == 1) {
             d2 = requant4_int(acc.a22[y][0], acc.a22[y][1], acc.a22[y][2], acc.a22[y][3], k.q22);
         } else if constexpr (MODE == A_INT && CONV == 2) {
@@ -153,12 +159,28 @@ __device__ __forceinline__ void c2_store(const C2Acc<ROWS> &acc, int R0, int cb,
                                k.q22);
         }
     };
+#ifdef QCNN_ABL_STRIPMAJOR  // diagnostic builds only (garbage image): the stores of a strip-major conc1 image -- pixel x goes
+    // to column x % 14 + 2 of strip x / 14 (864-byte rows, the rows of a strip contiguous), and the four columns two
+    // neighbouring strips share are stored twice
+    const int sm_strip = gx / 14, sm_col = gx - sm_strip * 14;
+    int8_t *sm_out = concf + ((size_t)(sm_strip % 106) * (H + 4) + gy0 + 2) * 864 + (sm_col + 2) * 48 + 12 * g;
+    const int sm_other = sm_col < 2 ? sm_strip - 1 : sm_col >= 12 ? sm_strip + 1 : -1;
+    int8_t *sm_out2 = concf + ((size_t)((sm_other < 0 ? 0 : sm_other) % 106) * (H + 4) + gy0 + 2) * 864 +
+                      (sm_col < 2 ? sm_col + 16 : sm_col - 12) * 48 + 12 * g;
+#endif
     if (gy0 + ROWS <= H && x0 + cb + 16 <= W) {  // the wave's pixels are all inside the frame
 #pragma unroll
         for (int y = 0; y < ROWS; ++y) {
             unsigned d0, d1, d2;
             quant_row(y, d0, d1, d2);
             unsigned *dst = reinterpret_cast<unsigned *>(out + y * row_bytes);
+#ifdef QCNN_ABL_STRIPMAJOR
+            dst = reinterpret_cast<unsigned *>(sm_out + y * 864);
+            if (sm_other >= 0) {
+                unsigned *dst2 = reinterpret_cast<unsigned *>(sm_out2 + y * 864);
+                dst2[0] = d0, dst2[1] = d1, dst2[2] = d2;
+            }
+#endif
 #ifdef QCNN_STAMP_ROWS  // diagnostic builds: a stamp behind the requantisation of every row (ahead of its store)
             C2_STAMP();
 #endif
@@ -596,6 +618,12 @@ void k_c1c2(const FusedArgs a)
                     // requant + store of pixel group k
                     auto c1_store = [&](int k, const v16i &d0, const v16i &d1) {
                         v4i o0, o1;
+#ifdef QCNN_ABL_NOC1REQ  // diagnostic builds only (garbage results): the producers' requantisation switched off
+                        if constexpr (true) {
+                            o0 = v4i{d0[0] ^ d0[4] ^ d0[8] ^ d0[12], d0[1] ^ d0[5] ^ d0[9] ^ d0[13], d0[2] ^ d0[6] ^ d0[10] ^ d0[14], d0[3] ^ d0[7] ^ d0[11] ^ d0[15]};
+                            o1 = v4i{d1[0] ^ d1[4] ^ d1[8] ^ d1[12], d1[1] ^ d1[5] ^ d1[9] ^ d1[13], d1[2] ^ d1[6] ^ d1[10] ^ d1[14], d1[3] ^ d1[7] ^ d1[11] ^ d1[15]};
+                        } else
+#endif
                         if constexpr (!EXACT) {
                             o0 = requant16_int(d0, q);
                             o1 = requant16_int(d1, q);
@@ -620,7 +648,13 @@ void k_c1c2(const FusedArgs a)
                                 o1 = v4i{0, 0, 0, 0};
                             }
                         }
-                        if (k + 1 < NK || last_valid[MODE]) {
+#ifdef QCNN_ABL_NOC1WRITE  // diagnostic builds only (garbage results): the C1 results are computed and not written to LDS
+                        asm volatile("" ::"v"(o0), "v"(o1));
+                        if (wrk < 0)
+#else
+                        if (k + 1 < NK || last_valid[MODE])
+#endif
+                        {
                             *reinterpret_cast<v4i *>(buf + wrk) = o0;         // channels 16h .. 16h+15
                             *reinterpret_cast<v4i *>(buf + (wrk ^ 32)) = o1;  // channels 32+16h .. 32+16h+15
                         }

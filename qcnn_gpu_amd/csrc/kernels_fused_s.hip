@@ -191,7 +191,12 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
         crow &= 7;
 #endif
         const unsigned lds_c = ring_s + grp * GROUP_BYTES + j * ROW_BYTES + share, lds_y = yring_s + (ygrp * R + j) * YSLOT;
+#ifdef QCNN_ABL_STRIPMAJOR  // diagnostic builds only (garbage results): what a strip-major conc1 image would give -- the
+        // rows of a strip follow one another in memory (864 contiguous bytes each); strips beyond the frame's image wrap
+        const int off_c = ((strip % 106) * (H + 4) + crow) * ROW_BYTES + share, off_y = yrow * W + x0;
+#else
         const int off_c = crow * row_bytes + xw * 48 + share, off_y = yrow * W + x0;
+#endif
         unsigned long long saved;
         // (m0 is written twice and is listed as clobbered, so the compiler keeps nothing of its own in it across the
         // block; between an s_mov to m0 and the LDS-direct load that reads it sits one other instruction, the wait

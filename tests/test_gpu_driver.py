@@ -313,6 +313,10 @@ def test_bench_launches_its_own_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["parity_vs_oracle"] is True and out["scaling"] == "weak"
     assert out["value"] > 0 and "roofline" in out
+    # one entry per rank: its own rate, and the device it ran on (both ranks on the one card here)
+    assert len(out["per_rank_mpixels_s"]) == 2 and all(v > 0 for v in out["per_rank_mpixels_s"])
+    assert len(out["per_rank_device"]) == 2 and len(out["per_rank_kernel_us"]) == 2
+    assert out["parity_frames_checked"] == 16            # every frame of both ranks
     n = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
     if n.stdout.strip() == "1":
         r = subprocess.run(base, capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
