@@ -104,6 +104,7 @@ struct qcnn_engine {
     int conc_frames = 0;          // capacity of conc1_int, in frames
     int group = 1;                // frames per kernel launch of forward_blu_batch
     bool tiled_b = false;         // QCNN_B_TILED=1: the tiled form of kernel B instead of the streaming one
+    bool wide_b = true;           // the streaming form with two column tiles per wave (QCNN_B_WIDE=0: one tile per wave)
     int8_t *wpack = nullptr;
     int *bias_i = nullptr;
     float *bias_f = nullptr;
@@ -625,6 +626,8 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     {
         const char *tb = getenv("QCNN_B_TILED");
         e->tiled_b = tb && atoi(tb) != 0;
+        const char *wb = getenv("QCNN_B_WIDE");
+        e->wide_b = !wb || atoi(wb) != 0;
     }
     const char *fx = getenv("QCNN_FORCE_EXACT");
     e->force_exact = fx ? atoi(fx) : 0;
@@ -764,6 +767,7 @@ static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nfr
     HIP_TRY(launch_fused_c1c2(a, e->path_a, e->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], e->stream));
     if (e->tiled_b) HIP_TRY(launch_fused_c3c4(a, e->path_b == PATH_FLOAT, e->stream));
+    else if (e->wide_b) HIP_TRY(launch_fused_c3c4_stream2(a, e->path_b == PATH_FLOAT, e->stream));
     else HIP_TRY(launch_fused_c3c4_stream(a, e->path_b == PATH_FLOAT, e->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[2], e->stream));
     return QCNN_OK;

@@ -219,13 +219,21 @@ vrcnn_stream::vrcnn_stream(char *orifile, char *inputfile, int frame_, int heigh
     }
 }
 
+// Leaves the process the way read_data does (message on stdout, status 1), from whichever thread found the problem:
+// the other threads of a streaming run are still using the GPU, so no destructor or atexit handler may run.
+static void die(void)
+{
+    fflush(stdout);
+    _exit(1);
+}
+
 static void read_fully(int fd, datatype *dst, size_t n, off_t at, int frame_no)
 {
     while (n > 0) {
         const ssize_t got = pread(fd, dst, n, at);
         if (got <= 0) {
             printf("short read at frame %d\n", frame_no);
-            exit(1);
+            die();
         }
         dst += got, at += got, n -= (size_t)got;
     }
@@ -264,7 +272,7 @@ void vrcnn_stream::write_frames(int first, int count, const datatype *recon) con
             const ssize_t put = pwrite(recon_fd, src, n, at);
             if (put <= 0) {
                 printf("write file failed\n");
-                exit(1);
+                die();
             }
             src += put, at += put, n -= (size_t)put;
         }

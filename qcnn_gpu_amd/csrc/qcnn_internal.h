@@ -234,6 +234,7 @@ hipError_t launch_conc_zero_border(void *conc_internal, int nframes, int H, int 
 hipError_t launch_fused_c1c2(const FusedArgs &a, int mode, hipStream_t s);  // 0 integer, 1 float pipeline, 2 clamped integer
 hipError_t launch_fused_c3c4(const FusedArgs &a, bool exact, hipStream_t s);         // tiled form (kernels_fused_b.hip)
 hipError_t launch_fused_c3c4_stream(const FusedArgs &a, bool exact, hipStream_t s);  // streaming form (kernels_fused_s.hip)
+hipError_t launch_fused_c3c4_stream2(const FusedArgs &a, bool exact, hipStream_t s);  // the same, two column tiles per wave (kernels_fused_s2.hip)
 
 // float32 configuration (kernels_float.hip)
 bool conv_float_supported(int cin, int cout, int ks);

@@ -454,42 +454,51 @@ def test_error_reporting():
     assert lib.qcnn_create(99, 1, 1, 8, 8, C.byref(h)) == -1     # no such device
 
 
-def test_tiled_kernel_b_still_selectable(monkeypatch):
-    """QCNN_B_TILED=1 (read when an engine is created) runs the tiled form of kernel B on the bordered conc1 image:
-    same bytes as the streaming form and the oracle, on a frame with ragged edges and on a batch."""
-    qp, h, w, nf = 32, 77, 131, 3
+@pytest.mark.parametrize("form", ["tiled", "one_tile", "two_tiles"])
+@pytest.mark.parametrize("exact", [0, 1])
+def test_every_form_of_kernel_b_is_selectable(form, exact, monkeypatch):
+    """The three forms of kernel B (read from the environment when an engine is created: QCNN_B_TILED=1 the tiled
+    form, QCNN_B_WIDE=0 the streaming form with one column tile per wave, default the streaming form with two) on the
+    bordered conc1 image, with integer epilogues and with the literal float pipeline: the bytes of the oracle, on
+    batches of frames with ragged edges (widths below, at and above one strip of 14 / 30 columns, single pixels)."""
+    qp = 32
     mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
-    frames = synth.synth_frames(h, w, qp, frames=nf, seed=5)[1]
-    want = [c_oracle.forward_blu(mb, np.ascontiguousarray(frames[i])) for i in range(nf)]
+    monkeypatch.setenv("QCNN_B_TILED", "1" if form == "tiled" else "0")
+    monkeypatch.setenv("QCNN_B_WIDE", "0" if form == "one_tile" else "1")
     lib = capi.load()
-    d_in, d_out = C.c_void_p(), C.c_void_p()
-    capi.check(lib.qcnn_dev_alloc(C.byref(d_in), nf * h * w))
-    capi.check(lib.qcnn_dev_alloc(C.byref(d_out), nf * h * w))
-    capi.check(lib.qcnn_dev_h2d(d_in, np.ascontiguousarray(frames).ctypes.data, nf * h * w))
-    for tiled in ("1", "0"):
-        monkeypatch.setenv("QCNN_B_TILED", tiled)
+    for h, w, nf in ((77, 131, 3), (5, 7, 2), (1, 1, 1), (33, 61, 2), (40, 30, 1), (64, 29, 1), (23, 14, 2), (20, 95, 1)):
+        frames = synth.synth_frames(h, w, qp, frames=nf, seed=5)[1]
+        want = [c_oracle.forward_blu(mb, np.ascontiguousarray(frames[i])) for i in range(nf)]
+        d_in, d_out = C.c_void_p(), C.c_void_p()
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_in), nf * h * w))
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_out), nf * h * w))
+        capi.check(lib.qcnn_dev_h2d(d_in, np.ascontiguousarray(frames).ctypes.data, nf * h * w))
         with qvrcnn(0, 1, 1, h, w) as net:
+            net.set_exact(exact)
             net.load_static_para(mb)
+            assert net.arith_paths == ((1, 1) if exact else (0, 0))
             capi.check(lib.qcnn_dev_memset(d_out, 0x5A, nf * h * w))
             net.forward_blu_batch(d_in.value, d_out.value, nf, h * w)
             net.synchronize()
             out = np.empty((nf, h, w), np.uint8)
             capi.check(lib.qcnn_dev_d2h(out.ctypes.data, d_out, nf * h * w))
             for i in range(nf):
-                assert np.array_equal(out[i], want[i]), f"QCNN_B_TILED={tiled} frame {i}"
-    capi.check(lib.qcnn_dev_free(d_in))
-    capi.check(lib.qcnn_dev_free(d_out))
+                assert np.array_equal(out[i], want[i]), f"{form} exact={exact} {w}x{h} frame {i}"
+        capi.check(lib.qcnn_dev_free(d_in))
+        capi.check(lib.qcnn_dev_free(d_out))
 
 
+@pytest.mark.parametrize("wide", ["0", "1"])
 @pytest.mark.parametrize("seg_rows", [1, 7, 24, 1000])
-def test_streaming_kernel_any_band_height(seg_rows, monkeypatch):
-    """The streaming kernel B cuts the frame into bands of rows (QCNN_SEG_ROWS overrides its own choice): bands of
-    1, 7, 24 rows and one band for the whole frame give the oracle's bytes, on a frame narrower than one strip of
-    14 columns, one of exactly three strips and a ragged one."""
+def test_streaming_kernel_any_band_height(seg_rows, wide, monkeypatch):
+    """The streaming kernel B (both forms: one and two column tiles per wave) cuts the frame into bands of rows
+    (QCNN_SEG_ROWS overrides its own choice): bands of 1, 7, 24 rows and one band for the whole frame give the oracle's
+    bytes, on a frame narrower than one strip (14 / 30 columns), frames of exactly three strips and ragged ones."""
     qp = 27
     mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
     monkeypatch.setenv("QCNN_SEG_ROWS", str(seg_rows))
-    for (h, w) in ((9, 5), (50, 42), (61, 99)):
+    monkeypatch.setenv("QCNN_B_WIDE", wide)
+    for (h, w) in ((9, 5), (50, 42), (61, 99), (37, 90), (44, 121)):
         y = _frame(h, w, qp, seed=h + w)
         rec_o, taps_o = c_oracle.forward_blu(mb, y, True)
         with qvrcnn(0, 1, 1, h, w) as net:
