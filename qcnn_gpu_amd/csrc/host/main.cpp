@@ -16,10 +16,10 @@
 //                      D2H per frame, as a three-stream pipeline over groups of frames, and the PSNR
 //                      sums on the device
 //   QCNN_STREAM=1      the pipelined frame loop on a clip that never sits in host memory whole: reader threads
-//                      (QCNN_STREAM_READERS, default 4) fill chunks of QCNN_STREAM_CHUNK frames (default: the
-//                      engine's frames per launch) by positioned reads, one worker per GPU runs
-//                      qcnn_forward_blu_clip on whole chunks, writer threads (QCNN_STREAM_WRITERS, default 2) write
-//                      the reconstruction, all at once; host buffers = (GPUs + readers + writers) chunks x 3.
+//                      (QCNN_STREAM_READERS, default 6) fill chunks of QCNN_STREAM_CHUNK frames (default: the
+//                      engine's frames per launch, at most 16 MiB) by positioned reads, QCNN_STREAM_ENGINES (default 2)
+//                      workers per GPU, each with an engine of its own, run qcnn_forward_blu_clip on whole chunks, writer threads (QCNN_STREAM_WRITERS, default 4) write
+//                      the reconstruction, all at once; host buffers = (workers + readers + writers) chunks x 3.
 //                      The time reported then INCLUDES reading and writing the files (the reference reads the
 //                      whole clip before its clock starts); a breakdown goes to stderr.
 //   QCNN_REPORT_RSS=1  print the peak resident set of the run on stderr when it ends
@@ -191,11 +191,11 @@ static void emit_record(char *input_fn, int frame, int height, int width, double
 // read, processed and written at the same time, so that host memory holds a few chunks instead of the clip
 // (vrcnn_data holds frame*h*w bytes three times: 3.1 GB for 500 frames of 1920x1080):
 //   readers   chunk c is read by reader c mod R with positioned reads (vrcnn_stream::read_frames) into slot c mod S
-//   workers   one per GPU; each takes the next chunk in order as soon as it is ready and runs it through
+//   workers   QCNN_STREAM_ENGINES per GPU; each takes the next chunk in order as soon as it is ready and runs it through
 //             qcnn_forward_blu_clip (H2D / fused kernels / D2H overlapped on three streams, integer SSE against
 //             the original on the device): whole chunks per GPU, whichever GPU is free first
 //   writers   chunk c is written by writer c mod W (reconstruction luma at its file offset), which frees the slot
-// A slot is reused once its previous chunk has been written: S = GPUs + readers + writers slots of three pinned
+// A slot is reused once its previous chunk has been written: S = workers + readers + writers slots of three pinned
 // buffers.  The per-frame sums stay in two small arrays, so the PSNR lines are printed in frame order at the end,
 // where the whole-clip path prints them.
 static void testqvrcnn_stream(char *ori_fn, char *input_fn, char *model_fn, int frame, int channel, int height, int width,
@@ -204,22 +204,34 @@ static void testqvrcnn_stream(char *ori_fn, char *input_fn, char *model_fn, int 
     using clk = std::chrono::steady_clock;
     const size_t fs = (size_t)channel * height * width;
     if (ngpu < 1) ngpu = 1;
+    // Two engines (and workers) per GPU by default: a chunk goes through qcnn_forward_blu_clip as one blocking call, H2D
+    // -> kernels -> D2H in a row, so a second engine on the same device is what lets the copies of one chunk run under
+    // the kernels of another.
+    int per_gpu = atoi(env_or("QCNN_STREAM_ENGINES", "2"));
+    per_gpu = per_gpu < 1 ? 1 : per_gpu > 4 ? 4 : per_gpu;
+    const int nworkers = ngpu * per_gpu;
     std::vector<qvrcnn *> nets;
-    for (int g = 0; g < ngpu; ++g) {
-        nets.push_back(new qvrcnn(device_of(g), 1, channel, height, width));
+    for (int k = 0; k < nworkers; ++k) {
+        nets.push_back(new qvrcnn(device_of(k % ngpu), 1, channel, height, width));
         nets.back()->load_static_para(model_fn);
     }
+    // frames per chunk: what one launch of the fused kernels covers, but at most 16 MiB of frames, so that large frames
+    // still make enough chunks for the three stages to overlap (and the host buffers stay well below 1 GB)
     int chunk = atoi(env_or("QCNN_STREAM_CHUNK", "0"));
-    if (chunk < 1) check(qcnn_batch_group(nets[0]->engine, 0, &chunk));
+    if (chunk < 1) {
+        check(qcnn_batch_group(nets[0]->engine, 0, &chunk));
+        const long long fit = (16ll << 20) / (long long)fs;
+        if (chunk > fit) chunk = fit < 1 ? 1 : (int)fit;
+    }
     if (chunk > frame) chunk = frame;
     const int nchunks = (frame + chunk - 1) / chunk;
     auto threads_of = [&](const char *name, const char *dflt) {
         const int n = atoi(env_or(name, dflt));
         return n < 1 ? 1 : n > 16 ? 16 : n > nchunks ? nchunks : n;
     };
-    const int R = threads_of("QCNN_STREAM_READERS", "4"), W = threads_of("QCNN_STREAM_WRITERS", "2");
-    const int S = ngpu + R + W < nchunks ? ngpu + R + W : nchunks;
-    for (int g = 0; g < ngpu; ++g) check(qcnn_clip_reserve(nets[g]->engine, chunk, 1));
+    const int R = threads_of("QCNN_STREAM_READERS", "6"), W = threads_of("QCNN_STREAM_WRITERS", "4");
+    const int S = nworkers + R + W < nchunks ? nworkers + R + W : nchunks;
+    for (int k = 0; k < nworkers; ++k) check(qcnn_clip_reserve(nets[k]->engine, chunk, 1));
     // slots: page-locked when the runtime grants it, ordinary memory otherwise
     std::vector<datatype *> buf(3 * (size_t)S, nullptr);
     bool pinned = true;
@@ -272,9 +284,9 @@ static void testqvrcnn_stream(char *ori_fn, char *input_fn, char *model_fn, int 
                 raise(ready, c);
             }
         });
-    for (int g = 0; g < ngpu; ++g)
+    for (int g = 0; g < nworkers; ++g)
         th.emplace_back([&, g] {
-            check(qcnn_set_device(device_of(g)));  // the current device is a per-thread setting
+            check(qcnn_set_device(device_of(g % ngpu)));  // the current device is a per-thread setting
             for (;;) {
                 const int c = next_chunk++;
                 if (c >= nchunks) break;
@@ -307,9 +319,9 @@ static void testqvrcnn_stream(char *ori_fn, char *input_fn, char *model_fn, int 
     }
     emit_record(input_fn, frame, height, width, vrcnn_data::psnr_from_sse(tb, io.nSize), vrcnn_data::psnr_from_sse(ta, io.nSize), us);
     fprintf(stderr,
-            "stream: %d frames in %d chunks of %d, %d slot(s) x 3 buffers = %.1f MB of %s host memory, %d reader(s), %d GPU worker(s), "
+            "stream: %d frames in %d chunks of %d, %d slot(s) x 3 buffers = %.1f MB of %s host memory, %d reader(s), %d GPU worker(s) on %d GPU(s), "
             "%d writer(s); busy: read %.1f ms, gpu %.1f ms, write %.1f ms; wall %.1f ms (file time included); max RSS %.1f MB\n",
-            frame, nchunks, chunk, S, 3.0 * S * chunk * fs / 1e6, pinned ? "page-locked" : "pageable", R, ngpu, W, read_us / 1e3,
+            frame, nchunks, chunk, S, 3.0 * S * chunk * fs / 1e6, pinned ? "page-locked" : "pageable", R, nworkers, ngpu, W, read_us / 1e3,
             gpu_us / 1e3, write_us / 1e3, us / 1e3, peak_rss_mb());
     for (datatype *p : buf) {
         if (pinned) qcnn_host_free_pinned(p);
