@@ -141,6 +141,8 @@ int qcnn_load_para_mem(qcnn_t *e, const void *image, size_t bytes);
  * quantize_out (:98, inference/cnn.cu:169-178), concat (:121, :140, inference/cnn.cu:285-320) and
  * adjustOutput(steps, ..) (:156) -- and everything else as written: adjustBasic before every
  * convolution, no activation after C1, ReLU after C2_x / C3_x, insert_w / insert_y, applyRes.
+ * (The literal text, static helpers included, runs through the C++ class API: qvrcnn::forward_shipped in
+ * include/qvrcnn.h, with the fields load_para does not set supplied by the caller.)
  * save_steps (:163) is a debug file append and is left to the caller.  Asynchronous on the engine
  * stream: the step bookkeeping runs on the device, no maximum travels to the host.  No float32 image
  * is written: each layer's convolution runs once for its largest |u| and once more with the

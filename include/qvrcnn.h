@@ -43,6 +43,12 @@ public:
     /* the same pass issued call by call through the layer objects, with the host round trips of the
      * reference (findMax copies every maximum to the host) */
     int forward_layers(void);
+    /* inference/qvrcnn.cu:82-167 as the shipped text reads, call by call through the layer objects: quantize_out_static
+     * (:100), concat_blu (:122, :141) and adjustOutput_static(.., 141, 16) (:157) inside the dynamic pass.  load_para sets
+     * none of the fields these read: the caller puts blu / mul / shift into the layer members and a step (>= 1) into
+     * C1.step_y first, as the reference's author must have done by hand.  (quantize_out_static does not relayout, so
+     * C1.v holds NCHW bytes that C2_x read as NCHW_VECT_C: the text is reproduced, not repaired.) */
+    int forward_shipped(void);
     int forward_blu(void);       /* inference/qvrcnn.cu:168-242, as the two fused gfx950 kernels */
     /* the same pass issued call by call through the layer objects, in the order and with the
      * buffers of inference/qvrcnn.cu:168-242 (every u / v / conc is materialised) */

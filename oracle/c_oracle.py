@@ -200,6 +200,26 @@ def forward_dynamic(model_bytes: bytes, y: np.ndarray, want_taps: bool = False):
     return (rec, taps) if want_taps else rec
 
 
+def forward_shipped(model_bytes: bytes, params, c1_step_y: int, y: np.ndarray):
+    """qvrcnn::forward as its shipped text reads (oracle/qcnn_oracle_dyn.c orc_forward_shipped): params = 6 x (blu, mul,
+    shift) the caller has put into the layer members, c1_step_y = the member C1.step_y.  Returns (rec, stepw, stepy,
+    step_y)."""
+    L = lib()
+    y = np.ascontiguousarray(y, np.uint8)
+    h, w = y.shape
+    rec = np.empty((h, w), np.uint8)
+    mb = np.frombuffer(model_bytes, np.uint8)
+    q = np.ascontiguousarray(np.asarray(params, np.int32).reshape(18))
+    stepw, stepy, step_y = np.zeros(4, np.int32), np.zeros(4, np.int32), np.zeros(6, np.int32)
+    L.orc_forward_shipped.restype = C.c_int
+    L.orc_forward_shipped.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_forward_shipped(_p(mb), mb.size, _p(q), int(c1_step_y), _p(y), h, w, _p(rec), _p(stepw), _p(stepy), _p(step_y))
+    if rc:
+        raise ValueError(f"orc_forward_shipped failed: {rc}")
+    return rec, stepw, stepy, step_y
+
+
 # ---- float32 configuration (oracle/qcnn_oracle_float.c) ---------------------------------------------------
 F_KS, F_CIN = (5, 3, 5, 3, 1, 3), (1, 64, 64, 48, 48, 48)
 

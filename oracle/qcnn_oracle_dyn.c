@@ -280,3 +280,78 @@ int orc_forward_dynamic(const uint8_t *model, long model_len, const uint8_t *y, 
         if (!t.u[l]) free(u[l]);
     return 0;
 }
+
+/* qvrcnn::forward exactly as the shipped text reads (inference/qvrcnn.cu:82-167), i.e. with the three static helpers it
+ * calls inside the dynamic pass: CovLayer::quantize_out_static (:100 -> mul_shift, inference/mat.cu:248-261: flat, NO
+ * relayout, so C1.v holds NCHW bytes that the next convolutions read as NCHW_VECT_C), ConcatLayer::concat_blu (:122, :141,
+ * which also sets step_y = ((1 << shift) + mul / 2) / mul, inference/cnn.cu:378-381) and adjustOutput_static(.., 141, 16)
+ * (:157).  load_para sets none of blu / mul / shift / C1.step_y: the caller supplies them (q = blu, mul, shift of the six
+ * layers; c1_step_y = the value of the member C1.step_y, which insert_y files at :105). */
+void orc_quant_blu(const float *u, int8_t *out, long HW, int C, int blu, int mul, int shift);
+int orc_forward_shipped(const uint8_t *model, long model_len, const int32_t *q, int c1_step_y, const uint8_t *y, int H, int W,
+                        uint8_t *rec, int32_t *stepw_out, int32_t *stepy_out, int32_t *step_y_out)
+{
+    if (model_len < orc_dyn_model_bytes()) return -1;
+    const int8_t *w[6];
+    float b[161], b_adj[161];
+    int step_w[6], step_y[6] = {0};
+    const uint8_t *p = model;
+    for (int l = 0; l < 6; ++l) {
+        int32_t sw;
+        memcpy(&sw, p, 4);
+        p += 4;
+        if (sw < 1) return -2;
+        step_w[l] = sw;
+        w[l] = (const int8_t *)p;
+        p += orc_layer_wsize(l);
+        for (int k = 0; k < DCOUT[l]; ++k) {
+            int32_t bi;
+            memcpy(&bi, p + 4 * k, 4);
+            b[DBOFF[l] + k] = (float)bi;
+        }
+        p += 4 * DCOUT[l];
+    }
+    if (c1_step_y < 1) return -3; /* adjustBasic would divide by it */
+    const long HW = (long)H * W;
+    int8_t *x_ppro = (int8_t *)malloc(4 * HW), *v1 = (int8_t *)malloc(64 * HW), *conc1 = (int8_t *)malloc(48 * HW);
+    int8_t *conc2 = (int8_t *)malloc(48 * HW), *v4 = (int8_t *)malloc(HW);
+    float *ua = (float *)malloc(sizeof(float) * 64 * HW), *uc = (float *)malloc(sizeof(float) * 32 * HW);
+    int stepw[4] = {0, 0, 0, 0}, stepy[4] = {0, 0, 0, 0};
+    step_y[0] = c1_step_y;
+
+    orc_ppro(y, x_ppro, HW);
+    /* layer 1 (:90-105): no activation, mul_shift into C1.v */
+    orc_adjust_basic(stepw, stepy, b, b_adj, 64, 0);
+    conv_dyn(x_ppro, 0, H, W, w[0], b_adj, 0, ua);
+    orc_mul_shift(ua, v1, 64 * HW, q[1], q[2]);
+    orc_insert_w(stepw, step_w[0], 1);
+    orc_insert_y(stepy, step_y[0], 1);
+    /* layers 2 and 3 (:108-143): ReLU, concat_blu */
+    const int8_t *in = v1;
+    for (int layer = 2; layer <= 3; ++layer) {
+        const int a = layer == 2 ? 1 : 3, c = a + 1;
+        int8_t *conc = layer == 2 ? conc1 : conc2;
+        orc_adjust_basic(stepw, stepy, b + DBOFF[a], b_adj + DBOFF[a], DCOUT[a], layer - 1);
+        orc_adjust_basic(stepw, stepy, b + DBOFF[c], b_adj + DBOFF[c], DCOUT[c], layer - 1);
+        conv_dyn(in, a, H, W, w[a], b_adj + DBOFF[a], 1, ua);
+        conv_dyn(in, c, H, W, w[c], b_adj + DBOFF[c], 1, uc);
+        step_y[a] = ((1 << q[3 * a + 2]) + q[3 * a + 1] / 2) / q[3 * a + 1];
+        step_y[c] = ((1 << q[3 * c + 2]) + q[3 * c + 1] / 2) / q[3 * c + 1];
+        orc_quant_blu(ua, conc, HW, DCOUT[a], q[3 * a], q[3 * a + 1], q[3 * a + 2]);
+        orc_quant_blu(uc, conc + (size_t)DCOUT[a] * HW, HW, DCOUT[c], q[3 * c], q[3 * c + 1], q[3 * c + 2]);
+        orc_insert_w(stepw, step_w[a], layer);
+        orc_insert_y(stepy, step_y[a], layer);
+        in = conc;
+    }
+    /* layer 4 and restore (:146-162) */
+    orc_adjust_basic(stepw, stepy, b + 160, b_adj + 160, 1, 3);
+    conv_dyn(conc2, 5, H, W, w[5], b_adj + 160, 0, ua);
+    orc_insert_w(stepw, step_w[5], 4);
+    orc_adjust_output_static(ua, v4, 141, 16, HW);
+    orc_apply_res(y, v4, rec, HW);
+    if (stepw_out) memcpy(stepw_out, stepw, sizeof stepw);
+    if (stepy_out) memcpy(stepy_out, stepy, sizeof stepy);
+    if (step_y_out) memcpy(step_y_out, step_y, sizeof step_y);
+    free(x_ppro), free(v1), free(conc1), free(conc2), free(v4), free(ua), free(uc);
+    return 0;
+}

@@ -171,6 +171,48 @@ int qvrcnn::forward_layers(void)
     return 0;
 }
 
+int qvrcnn::forward_shipped(void)
+{
+    // the statement sequence of inference/qvrcnn.cu:82-167 exactly as shipped (the calls of :100, :122, :141, :157)
+    int layer = 0;
+    check(qcnn_dev_sync());
+    I1.ppro();
+    layer = 1;
+    adjustBasic(steps, (btype *)C1.b, (btype *)C1.b_adj, C1.outChannel, layer - 1);
+    C1.ConvForward(cudnnHandle, I1.xDesc, I1.x_ppro, workspace, workspaceSize);
+    C1.quantize_out_static();
+    insert_w(C1.step_w, layer);
+    insert_y(C1.step_y, layer);
+    layer = 2;
+    adjustBasic(steps, (btype *)C2_1.b, (btype *)C2_1.b_adj, C2_1.outChannel, layer - 1);
+    adjustBasic(steps, (btype *)C2_2.b, (btype *)C2_2.b_adj, C2_2.outChannel, layer - 1);
+    C2_1.ConvForward(cudnnHandle, C1.vDesc, C1.v, workspace, workspaceSize);
+    C2_1.activate(cudnnHandle);
+    C2_2.ConvForward(cudnnHandle, C1.vDesc, C1.v, workspace, workspaceSize);
+    C2_2.activate(cudnnHandle);
+    Conc1.concat_blu(&C2_1, &C2_2);
+    insert_w(C2_1.step_w, layer);
+    insert_y(C2_1.step_y, layer);
+    layer = 3;
+    adjustBasic(steps, (btype *)C3_1.b, (btype *)C3_1.b_adj, C3_1.outChannel, layer - 1);
+    adjustBasic(steps, (btype *)C3_2.b, (btype *)C3_2.b_adj, C3_2.outChannel, layer - 1);
+    C3_1.ConvForward(cudnnHandle, Conc1.concDesc, Conc1.conc, workspace, workspaceSize);
+    C3_1.activate(cudnnHandle);
+    C3_2.ConvForward(cudnnHandle, Conc1.concDesc, Conc1.conc, workspace, workspaceSize);
+    C3_2.activate(cudnnHandle);
+    Conc2.concat_blu(&C3_1, &C3_2);
+    insert_w(C3_1.step_w, layer);
+    insert_y(C3_1.step_y, layer);
+    layer = 4;
+    adjustBasic(steps, (btype *)C4.b, (btype *)C4.b_adj, C4.outChannel, layer - 1);
+    C4.ConvForward(cudnnHandle, Conc2.concDesc, Conc2.conc, workspace, workspaceSize);
+    insert_w(C4.step_w, layer);
+    adjustOutput_static((convtype *)C4.u, (xwtype *)C4.v, 141, 16, C4.uSize);
+    I1.applyRes((xwtype *)C4.v);
+    check(qcnn_dev_sync());
+    return 0;
+}
+
 int qvrcnn::backward(void)
 {
     printf("qvrcnn::backward: not available (declared in inference/qvrcnn.cuh:33, defined nowhere)\n");

@@ -9,6 +9,7 @@
 //   <out>.dynlayers   x_rec of qvrcnn::forward_layers    (layer objects, host round trips)
 //   <out>.b_adj       the file qvrcnn::save_b_adj appends
 //   <out>.c1dyn       C1.v of a stand-alone CovLayer through load_para / ConvForward / quantize_out
+//   <out>.shipped     x_rec of qvrcnn::forward_shipped   (the literal text of inference/qvrcnn.cu:82-167)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
@@ -110,6 +111,17 @@ int main(int argc, char **argv)
         dump(out + ".c1dyn", D1.v, (size_t)64 * H * W);
         printf("standalone step_w %d step_y %d max_u %d\n", D1.step_w, D1.step_y, D1.max_u);
         check(qcnn_dev_free(ws));
+
+        // qvrcnn::forward as its shipped text reads (inference/qvrcnn.cu:100,122,141,157): the layer members still hold
+        // blu / mul / shift of the static model loaded first; C1.step_y is set by hand, as the text needs
+        check(qcnn_dev_memset(net.I1.x_rec, 0, (size_t)H * W));
+        for (int k = 0; k < LAYER; ++k) net.steps.stepw[k] = net.steps.stepy[k] = 0;
+        net.C1.step_y = 37;
+        net.forward_shipped();
+        dump(out + ".shipped", net.I1.x_rec, (size_t)H * W);
+        printf("shipped steps w %d %d %d %d y %d %d %d %d step_y %d %d %d %d\n", net.steps.stepw[0], net.steps.stepw[1],
+               net.steps.stepw[2], net.steps.stepw[3], net.steps.stepy[0], net.steps.stepy[1], net.steps.stepy[2], net.steps.stepy[3],
+               net.C2_1.step_y, net.C2_2.step_y, net.C3_1.step_y, net.C3_2.step_y);
     }
     printf("psnr before %.6f after %.6f\n", d.psnr(d.input), 0.0);
     return 0;

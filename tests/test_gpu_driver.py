@@ -179,6 +179,12 @@ def test_cpp_dynamic_layer_api_matches_oracle(tmp_path):
     sy, mu = t["step_y"], t["max_u"]
     assert "dyn step_y %d %d %d %d %d max_u %d %d" % (sy[0], sy[1], sy[2], sy[3], sy[4], mu[0], mu[4]) in r.stdout
     assert "standalone step_w %d step_y %d max_u %d" % (dm.layers[0].step_w, sy[0], mu[0]) in r.stdout
+    # qvrcnn::forward as its shipped text reads (quantize_out_static, concat_blu, adjustOutput_static(.., 141, 16) inside
+    # the dynamic pass, inference/qvrcnn.cu:100,122,141,157) against the oracle's literal restatement
+    rec_s, stepw, stepy, step_y = c_oracle.forward_shipped(dm.to_bytes(), synth.QUANT_TRIPLES[qp], 37, anc[0])
+    assert np.array_equal(np.fromfile(str(out) + ".shipped", np.uint8).reshape(h, w), rec_s)
+    assert ("shipped steps w %d %d %d %d y %d %d %d %d step_y %d %d %d %d" % (*stepw, *stepy, *step_y[1:5])) in r.stdout
+    assert not np.array_equal(rec_s, rec_o)          # it is a different pass, not an alias of forward()
 
 
 def test_driver_dynamic_mode(tmp_path):
