@@ -554,7 +554,7 @@ void k_c1c2(const FusedArgs a)
                     c2_mfma<EXACT, C2_BLOCK_ROWS - C2_CONS_ROWS>(acc, smem + ((n - 1) & 1) * SC1_BYTES, R0 + C2_CONS_ROWS, cb, c, g, w22, w21, kc,
                                                      [] {});
                     c2_store<PATH, C2_BLOCK_ROWS - C2_CONS_ROWS>(acc, R0 + C2_CONS_ROWS, cb, c, g, kc,
-                                                      a.conc1 + (size_t)prev.f * a.conc_stride, prev.tx * TW, prev.ty * TH, H, W);
+                                                      a.conc1 + QCNN_CONC_OFF(a, prev.f), prev.tx * TW, prev.ty * TH, H, W);
                 }
             }
         };
@@ -719,7 +719,7 @@ void k_c1c2(const FusedArgs a)
             bool have = false;
             auto store_held = [&] {
                 if (have)
-                    c2_store<PATH, C2_ROWS, CONV>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)held.f * a.conc_stride, held.tx * TW,
+                    c2_store<PATH, C2_ROWS, CONV>(acc, R0c, cb, c, g, kc, a.conc1 + QCNN_CONC_OFF(a, held.f), held.tx * TW,
                                                    held.ty * TH, H, W);
             };
             auto store_then_release = [&] {
@@ -743,7 +743,7 @@ void k_c1c2(const FusedArgs a)
                         set_prio<C2_PRIO_N_MFMA>();
                         c2_mfma<EXACT, C2_ROWS, CONV>(acc, buf, R0c, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
                         set_prio<C2_PRIO_N_VALU>();
-                        c2_store<PATH, C2_ROWS, CONV>(acc, R0c, cb, c, g, kc, a.conc1 + (size_t)pos.f * a.conc_stride, pos.tx * TW,
+                        c2_store<PATH, C2_ROWS, CONV>(acc, R0c, cb, c, g, kc, a.conc1 + QCNN_CONC_OFF(a, pos.f), pos.tx * TW,
                                                        pos.ty * TH, H, W);
                     }
 #endif

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
             if (tl) {
                 const int x0 = p0.tx * TW, y0 = p0.ty * TH;
                 direct = y0 >= 2 && y0 - 2 + INR <= H && x0 >= 2 && x0 - 2 + INC <= W;
-                org = a.conc1 + (size_t)p0.f * a.conc_stride + ((ptrdiff_t)y0 * conc_wp(W) + x0) * 48;  // image (y0-2, x0-2)
+                org = a.conc1 + QCNN_CONC_OFF(a, p0.f) + ((ptrdiff_t)y0 * conc_wp(W) + x0) * 48;  // image (y0-2, x0-2)
             }
             auto request = [&](auto itc) {  // direct load of the 64 pieces this wave owns in group `it`
                 constexpr int it = decltype(itc)::value;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(KB_THREADS) void k_c3c4(const FusedArgs a)
             // outside the frame zeroed, then LDS buffer n&1.  Rare, so its load latency is not hidden.
             if (tl && !direct) {
                 const int x0 = p0.tx * TW, y0 = p0.ty * TH;
-                const int8_t *frame = a.conc1 + (size_t)p0.f * a.conc_stride;
+                const int8_t *frame = a.conc1 + QCNN_CONC_OFF(a, p0.f);
                 v4i v[ITER];
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {

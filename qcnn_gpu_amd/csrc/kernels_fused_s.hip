@@ -164,7 +164,7 @@ void k_c3c4s(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_u
     // 1 + 3 * 10 = 31 instructions may still be in flight.
     const int row_bytes = conc_wp(W) * 48;
     const __amdgpu_buffer_rsrc_t conc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t *>(a.conc1 + (size_t)f * a.conc_stride), 0, (int)a.conc_stride, 0x00020000);
+        const_cast<int8_t *>(a.conc1 + QCNN_CONC_OFF(a, f)), 0, (int)a.conc_stride, 0x00020000);
     // residual input and output go through buffer descriptors of the frame (at most 2^30 bytes): a scalar row
     // offset plus the lane's column, or an offset past the end for the lanes that own no pixel
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(

@@ -124,7 +124,7 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
     // columns outside the frame, which are masked.)
     const int row_bytes = conc_wp(W) * 48;
     const __amdgpu_buffer_rsrc_t conc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t *>(a.conc1 + (size_t)f * a.conc_stride), 0, (int)a.conc_stride, 0x00020000);
+        const_cast<int8_t *>(a.conc1 + QCNN_CONC_OFF(a, f)), 0, (int)a.conc_stride, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(a.y + (size_t)f * a.frame_stride), 0, H * W, 0x00020000);
     const __amdgpu_buffer_rsrc_t rec_rsrc =

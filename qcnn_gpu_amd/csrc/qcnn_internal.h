@@ -120,6 +120,14 @@ struct PackedOffsets {
     static constexpr int TOTAL = C4W9 + 1024;
 };
 
+// Byte offset of frame f's conc1 image.  -DQCNN_ABL_ONECONC (a measurement build whose results are garbage) puts every
+// frame of a launch into the first image, which then stays in the 256 MiB last-level cache between its writer and its reader.
+#ifdef QCNN_ABL_ONECONC
+#define QCNN_CONC_OFF(a, f) ((size_t)0)
+#else
+#define QCNN_CONC_OFF(a, f) ((size_t)(f) * (a).conc_stride)
+#endif
+
 // Arguments of the fused kernels (passed by value).
 struct FusedArgs {
     const uint8_t *y;        // I1.x       uint8 [H][W]
