@@ -618,8 +618,8 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     HIP_TRY_E(hipMemset(e->dbg, 0, 48 * e->HW));
 #endif
 #ifdef QCNN_STAMPS
-    HIP_TRY_E(hipMalloc(&e->dbg, 24 * 128 * sizeof(unsigned long long)));
-    HIP_TRY_E(hipMemset(e->dbg, 0, 24 * 128 * sizeof(unsigned long long)));
+    HIP_TRY_E(hipMalloc(&e->dbg, (24 * 128 + 3 * 16384) * sizeof(unsigned long long)));
+    HIP_TRY_E(hipMemset(e->dbg, 0, (24 * 128 + 3 * 16384) * sizeof(unsigned long long)));
 #endif
     for (int l = 0; l < 6; ++l) HIP_TRY_E(hipMalloc(&e->w_file[l], wsize(l)));
 #undef HIP_TRY_E
@@ -1384,6 +1384,14 @@ int qcnn_debug_stamps(qcnn_t *e, unsigned long long *host_out)
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(host_out, e->dbg, 24 * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(e->dbg, 0, 24 * 128 * sizeof(unsigned long long)));
+    return QCNN_OK;
+}
+// diagnostic builds only: start tick, end tick and hardware id of the first 16384 workgroups of the last kernel B launch
+int qcnn_debug_blocks(qcnn_t *e, unsigned long long *host_out)
+{
+    if (!e || !host_out) return fail(QCNN_E_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(host_out, e->dbg + 24 * 128, 3 * 16384 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return QCNN_OK;
 }
 #endif

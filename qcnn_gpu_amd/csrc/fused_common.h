@@ -203,6 +203,32 @@ __device__ __forceinline__ void requant12_piece(int a, int b, int c, const Requa
     }
 }
 
+// One value of the integer requantiser: its two instructions, into byte I of `p` (I = 0 starts the dword).  A caller
+// that places one of these behind every MFMA hides the requantiser in the matrix pipe's shadow.  The same rules as
+// for requant12_piece hold: the accumulator complete for the latency of its MFMA, and a wait state (any
+// instruction) between the write of byte 3 and a vector instruction that reads the dword.
+template <int I>
+__device__ __forceinline__ void requant1(int a, int mulk, unsigned &p)
+{
+    int t;
+    if constexpr (I == 0) {
+        asm("v_mad_i32_i24 %1, %2, %3, 0 clamp\n\t"
+            "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"
+            : "=&v"(p), "=&v"(t)
+            : "v"(a), "s"(mulk));
+    } else {
+#define QCNN_REQ_ONE(SEL)                                                                                             \
+    asm("v_mad_i32_i24 %1, %2, %3, 0 clamp\n\t"                                                                       \
+        "v_max_i32_sdwa %0, sext(%1), 0 dst_sel:" SEL " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD"    \
+        : "+v"(p), "=&v"(t)                                                                                           \
+        : "v"(a), "s"(mulk))
+        if constexpr (I == 1) QCNN_REQ_ONE("BYTE_1");
+        else if constexpr (I == 2) QCNN_REQ_ONE("BYTE_2");
+        else QCNN_REQ_ONE("BYTE_3");
+#undef QCNN_REQ_ONE
+    }
+}
+
 // The same for the 16 channels of one 32x32 accumulator (four dwords, one requantiser).
 __device__ __forceinline__ v4i requant16_int(const v16i &d, const Requant &q)
 {

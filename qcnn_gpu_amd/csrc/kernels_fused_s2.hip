@@ -20,8 +20,25 @@
 //     to the column left of it), so they are overwritten with tile 1's values of the same lanes and the gather
 //     addresses wrap modulo 16: one select, and tile 0 yields all 16 of its outputs; tile 1 yields 14.
 //   * every phase of the software-pipelined row runs for tile 0, then for tile 1.
+//
+// Scheduling (measured with the diagnostic builds of tools/stamps_s2.py):
+//   * a launch is sized to ONE round of waves where it can be (2048 units on 256 CUs), and the launch lasts as long
+//     as its slowest wave.  The two waves of a SIMD are not equals: the older one wins every arbitration and used to
+//     finish after 0.70 of the time the younger one needed, which then ran alone on a SIMD it cannot fill.  The
+//     younger wave therefore runs every other row at priority 1: both finish together.
+//   * the strips at the left and right frame edge used to run every row through the tested form and ended 20 % after
+//     the others; they now run the steps in the middle of a band through a form that only masks the region columns
+//     outside the frame.
+//   * on the integer path the requantiser's two instructions per value sit one value behind every MFMA (rowi below),
+//     which is what the matrix pipe lets the vector port issue in an MFMA's shadow.
 #define STAMP_ROW (wv + 12)
+#include <climits>
+
 #include "fused_common.h"
+#ifdef QCNN_STAMPS_NOPH  // diagnostic builds that time whole workgroups only
+#undef STAMP
+#define STAMP() do { } while (0)
+#endif
 
 namespace qcnn {
 
@@ -55,7 +72,7 @@ __device__ __forceinline__ int lane_of_pixel2(int pix, int g)
 
 template <bool EXACT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_units)
+void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_units, int second_from)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS];
     const int lane = threadIdx.x & 63;
@@ -64,6 +81,13 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
     const int per_xcd = gridDim.x >> 3;
     int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (unit >= total_units) return;
+    // In a launch of one round the workgroups an XCD receives first land one on every SIMD, the later ones second:
+    // those are the younger waves (second_from = SIMDs of an XCD; INT_MAX in a launch of several rounds).
+    const bool young = (int)(blockIdx.x >> 3) >= second_from;
+#ifdef QCNN_STAMPS  // diagnostic builds only: when and where this workgroup ran
+    unsigned long long blk_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t0)::"memory");
+#endif
     // (the divisions run on the vector ALU: readfirstlane brings the wave-uniform results back to scalar registers,
     // which the buffer descriptors and scalar offsets below need)
     const int strip = __builtin_amdgcn_readfirstlane(unit % nstrips);
@@ -234,15 +258,24 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
     STAMP_INIT();
     const int wv = 0;
     (void)wv;
-    // One conc1 row for both tiles; see the one-tile form for the software pipeline.  CHECK = false: a step whose six
-    // conc2 rows lie inside the frame and whose six output rows lie inside the band, in a strip with no column
-    // outside the frame.
-    // (always inlined: called from three loops, and as a function of its own it would take its wave-uniform operands
-    // in vector registers)
-    auto row = [&](auto jc, auto checkc, int t) __attribute__((always_inline)) {
+    // One conc1 row for both tiles; see the one-tile form for the software pipeline.  MODE 0: a step whose six conc2
+    // rows lie inside the frame and whose six output rows lie inside the band, in a strip with no column outside the
+    // frame; MODE 2: such a step in a strip at the frame edge (region columns outside the frame masked); MODE 1:
+    // everything tested.  This form serves the float path; the integer path runs rowi below.
+    // (always inlined: called from several loops, and as a function of its own it would take its wave-uniform
+    // operands in vector registers)
+    auto prio = [&](auto jc) __attribute__((always_inline)) {
+        if (young) {
+            if constexpr (decltype(jc)::value & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    auto row = [&](auto jc, auto modec, int t) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        constexpr bool CHECK = decltype(checkc)::value;
+        constexpr int MODE = decltype(modec)::value;
+        constexpr bool CHECK = MODE == 1, COLS = MODE != 0;
         const int m0 = R * t;
+        prio(jc);
         const unsigned char *rdc = rd + g3 * GROUP_BYTES, *rdo = rd + g3n * GROUP_BYTES;
         static_assert(R % 2 == 0 && R % 3 == 0, "the fragment and accumulator slots repeat with the step");
         v4i(&B)[NT][3] = Bq[j & 1];
@@ -274,7 +307,7 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
             P[T] = Pa[T] + D4p[T][2];
-            if constexpr (CHECK) P[T] &= colmask[T];
+            if constexpr (COLS) P[T] &= colmask[T];
             Pa[T] = Pb[T] + D4p[T][1];
             Pb[T] = D4p[T][0];
         }
@@ -368,10 +401,155 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
         }
         STAMP();
     };
-    // Steps [t_lo, t_hi) need no test (see the one-tile form): conc2 rows inside the frame, output rows inside the
-    // band, requested rows inside the frame / the bordered image, no column of the strip outside the frame.
-    int t_lo = T_steps, t_hi = T_steps;
-    if (!edge_strip) {
+    // The row of the integer path: the same work with the requantiser spread over the matrix instructions, one value
+    // (two vector instructions) behind every MFMA, and applyRes_y one instruction per gap.  The C4 MFMAs of a conc2 row
+    // move to the start of the next row (dq carries the packed row instead of D4p its products).
+    unsigned dq[NT][3] = {{0, 0, 0}, {0, 0, 0}};
+#if defined(QCNN_STAMPS) && !defined(QCNN_STAMPS_NOPH)  // diagnostic builds only: cycles per phase of a row, summed over the MODE 0 rows of one wave
+#define QCNN_PH 1
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_prev = 0, ph_rows = 0;
+#define PH(K)                                                                                     \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        if (MODE == 0) ph[K] += t_ - ph_prev;                                                     \
+        ph_prev = t_;                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define PH(K) do { } while (0)
+#endif
+    auto rowi = [&](auto jc, auto modec, int t) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int MODE = decltype(modec)::value;
+        constexpr bool CHECK = MODE == 1, COLS = MODE != 0;
+        const int m0 = R * t;
+        const unsigned char *rdc = rd + g3 * GROUP_BYTES, *rdo = rd + g3n * GROUP_BYTES;
+        v4i(&B)[NT][3] = Bq[j & 1];
+        v4i(&Bn)[NT][3] = Bq[(j + 1) & 1];
+        prio(jc);
+        PH(7);
+        if (CHECK && t >= T_steps - 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+        PH(0);
+        constexpr int s0 = j % 3, s1 = (j + 2) % 3, s2 = (j + 1) % 3;
+        constexpr int cur = j % 2, prv = (j + 1) % 2;
+        const int y2 = ya - 3 + m0 + j;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef QCNN_ABL_FINE_NORQ  // diagnostic builds only (garbage results)
+#define RQ32(T, I, HALF) dq[T][1 + HALF] ^= a32[T][prv][HALF][I]
+#define RQ31(T, I) dq[T][0] ^= acc[T][s2][I]
+#else
+#define RQ32(T, I, HALF) requant1<I>(a32[T][prv][HALF][I], q32.mulk, dq[T][1 + HALF])
+#define RQ31(T, I) requant1<I>(acc[T][s2][I], q31.mulk, dq[T][0])
+#endif
+#ifdef QCNN_ABL_FINE_NOMFMA  // diagnostic builds only (garbage results)
+#define mfma16 [](v4i A_, v4i B_, v4i C_) { return v4i{C_[0] ^ B_[0], C_[1] ^ A_[1], C_[2], C_[3]}; }
+#endif
+        // C4 of conc2 row y2 - 1, requantised by the previous row (a row outside the frame is C4's zero padding)
+        v4i D4[NT];
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            if (!CHECK || (unsigned)(y2 - 1) < (unsigned)H)
+                D4[T] = mfma16(f4, v4i{(int)dq[T][0], (int)dq[T][1], (int)dq[T][2], 0}, v4i{0, 0, 0, 0});
+            else D4[T] = v4i{0, 0, 0, 0};
+        }
+        int yv[NT];
+#pragma unroll
+        for (int T = 0; T < NT; ++T) yv[T] = *reinterpret_cast<const int *>(rdy[T] + j * YSLOT);
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                Bn[T][s] = *reinterpret_cast<const v4i *>((j + 1 < R ? rdc + (j + 1) * ROW_BYTES : rdo) + (16 * T + s) * 48);
+        SB();
+        // third kernel row of conc2 row y2 (complete with it)
+        acc[0][s2] = mfma16(f31[0][2], B[0][0], acc[0][s2]); SB(); RQ32(0, 0, 0); SB();
+        acc[1][s2] = mfma16(f31[0][2], B[1][0], acc[1][s2]); SB(); RQ32(1, 0, 0); SB();
+        acc[0][s2] = mfma16(f31[1][2], B[0][1], acc[0][s2]); SB(); RQ32(0, 0, 1); SB();
+        acc[1][s2] = mfma16(f31[1][2], B[1][1], acc[1][s2]); SB(); RQ32(1, 0, 1); SB();
+        // C4 sums of output row y3 = y2 - 2: out[o] = P_0[o] + P_1[o + 1] + P_2[o + 2] (lane rows 0, 1, 2)
+        int P[NT], v1[NT], v2[NT];
+        acc[0][s2] = mfma16(f31[2][2], B[0][2], acc[0][s2]); SB();
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            P[T] = Pa[T] + D4[T][2];
+            if constexpr (COLS) P[T] &= colmask[T];
+        }
+        SB();
+        acc[1][s2] = mfma16(f31[2][2], B[1][2], acc[1][s2]); SB();
+        PH(1);
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            Pa[T] = Pb[T] + D4[T][1];
+            Pb[T] = D4[T][0];
+        }
+        {
+            const int M0 = borrow ? P[1] : P[0];  // tile 0's gathers wrap into tile 1's first pixels
+            v1[0] = __builtin_amdgcn_ds_bpermute(addr1, M0);
+            v2[0] = __builtin_amdgcn_ds_bpermute(addr2, M0);
+            v1[1] = __builtin_amdgcn_ds_bpermute(addr1, P[1]);
+            v2[1] = __builtin_amdgcn_ds_bpermute(addr2, P[1]);
+        }
+        SB();
+        const int y3 = y2 - 2;
+        // second kernel row of conc2 row y2 + 1; from here on the C3_1 channels of row y2 are requantised too
+        acc[0][s1] = mfma16(f31[0][1], B[0][0], acc[0][s1]); SB(); RQ32(0, 1, 0); SB();
+        acc[1][s1] = mfma16(f31[0][1], B[1][0], acc[1][s1]); SB(); RQ32(1, 1, 0); SB();
+        acc[0][s1] = mfma16(f31[1][1], B[0][1], acc[0][s1]); SB(); RQ32(0, 1, 1); RQ31(0, 0); SB();
+        acc[1][s1] = mfma16(f31[1][1], B[1][1], acc[1][s1]); SB(); RQ32(1, 1, 1); RQ31(1, 0); SB();
+        acc[0][s1] = mfma16(f31[2][1], B[0][2], acc[0][s1]); SB(); RQ32(0, 2, 0); RQ31(0, 1); SB();
+        acc[1][s1] = mfma16(f31[2][1], B[1][2], acc[1][s1]); SB(); RQ32(1, 2, 0); RQ31(1, 1); SB();
+        PH(2);
+        // first kernel row of conc2 row y2 + 2 (the bias starts the accumulator); applyRes_y of output row y3, one
+        // instruction per gap
+        int sum[NT], temp[NT], out[NT];
+        acc[0][s0] = mfma16(f31[0][0], B[0][0], b0); SB(); RQ32(0, 2, 1); RQ31(0, 2); SB();
+        acc[1][s0] = mfma16(f31[0][0], B[1][0], b0); SB(); RQ32(1, 2, 1); RQ31(1, 2); SB();
+        acc[0][s0] = mfma16(f31[1][0], B[0][1], acc[0][s0]); SB(); RQ32(0, 3, 0); sum[0] = P[0] + v1[0] + v2[0]; SB();
+        acc[1][s0] = mfma16(f31[1][0], B[1][1], acc[1][s0]); SB(); RQ32(1, 3, 0); sum[1] = P[1] + v1[1] + v2[1]; SB();
+        acc[0][s0] = mfma16(f31[2][0], B[0][2], acc[0][s0]); SB(); RQ32(0, 3, 1); temp[0] = __mul24(sum[0], mul) + round4v; SB();
+        acc[1][s0] = mfma16(f31[2][0], B[1][2], acc[1][s0]); SB(); RQ32(1, 3, 1); temp[1] = __mul24(sum[1], mul) + round4v; SB();
+        PH(3);
+        // C3_2 of conc2 row y2 + 1 (its centre pixel): requantised by the next row
+        a32[0][cur][0] = mfma16(f32[0], B[0][1], b1); SB(); RQ31(0, 3); temp[0] >>= shift; SB();
+        a32[1][cur][0] = mfma16(f32[0], B[1][1], b1); SB(); RQ31(1, 3); temp[1] >>= shift; SB();
+        a32[0][cur][1] = mfma16(f32[1], B[0][1], b2); SB(); temp[0] += yv[0]; temp[1] += yv[1]; SB();
+        a32[1][cur][1] = mfma16(f32[1], B[1][1], b2); SB(); out[0] = min(max(temp[0], 0), 255); out[1] = min(max(temp[1], 0), 255); SB();
+        PH(4);
+        // the stores (only if the row lies in the band)
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            const int voff = (!CHECK || (y3 >= ya && y3 < yb)) ? out_off[T] : OOB;
+            asm volatile("buffer_store_byte %0, %1, %2, %3 offen" ::"v"(out[T]), "v"(voff), "s"(rec_rsrc), "s"(y3 * W) : "memory");
+        }
+        PH(5);
+        // then the requests for the slots this row has emptied (rows past the last one the band walks are not
+        // requested: when the wave ends and its LDS is handed to the next workgroup, no load may still be on its way
+        // into it; the last step but one still fetches the Y pixels of the last step)
+#ifdef QCNN_ABL_FINE_NOLOAD  // diagnostic builds only (garbage results)
+        if (!CHECK || t <= T_steps - 2) request_impl(false, g3, j, 0, y3 + R, true);
+#else
+        if (!CHECK || t <= T_steps - 3) request_impl(true, g3, j, ya + m0 + j + 2 * R, y3 + R, CHECK);
+        else if (t == T_steps - 2) request_impl(false, g3, j, 0, y3 + R, true);
+#endif
+        SB();
+        PH(6);
+#ifdef QCNN_PH
+        if (MODE == 0) ++ph_rows;
+#endif
+#undef SB
+#undef RQ32
+#undef RQ31
+#ifdef QCNN_ABL_FINE_NOMFMA
+#undef mfma16
+#endif
+    };
+    // Steps [t_lo, t_hi) need no test of rows (see the one-tile form): conc2 rows inside the frame, output rows inside
+    // the band, requested rows inside the frame / the bordered image.
+    int t_lo, t_hi;
+    {
         int last = (H + 3 - R - ya < yb + 5 - R - ya ? H + 3 - R - ya : yb + 5 - R - ya);
         last = last < H + 5 - 3 * R - ya ? last : H + 5 - 3 * R - ya;
         last = last < H + 4 - 3 * R - ya ? last : H + 4 - 3 * R - ya;
@@ -380,19 +558,42 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
         if (t_hi > T_steps - 2) t_hi = T_steps - 2 > 0 ? T_steps - 2 : 0;  // the last two steps request nothing
         if (t_lo > t_hi) t_lo = t_hi;
     }
+    // (four explicit loops: with the step wrapped in a lambda of its own the compiler spills registers)
+#define QCNN_STEP(M)                                                            \
+    do {                                                                        \
+        static_for<R>([&](auto jc) {                                            \
+            if constexpr (EXACT) row(jc, std::integral_constant<int, M>{}, t);  \
+            else rowi(jc, std::integral_constant<int, M>{}, t);                 \
+        });                                                                     \
+        g3 ^= 1, g3n ^= 1;                                                      \
+    } while (0)
     int t = 0;
-    for (; t < t_lo; ++t) {
-        static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
-        g3 ^= 1, g3n ^= 1;
+    for (; t < t_lo; ++t) QCNN_STEP(1);
+    if (edge_strip)
+        for (; t < t_hi; ++t) QCNN_STEP(2);
+    for (; t < t_hi; ++t) QCNN_STEP(0);
+    for (; t < T_steps; ++t) QCNN_STEP(1);
+#undef QCNN_STEP
+    __builtin_amdgcn_s_setprio(0);
+#ifdef QCNN_STAMPS
+    if (a.dbg && blockIdx.x < 16384 && lane == 0) {
+        unsigned long long blk_t1;
+        unsigned hwid, xcc;
+        asm volatile("s_memtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(blk_t1), "=s"(hwid), "=s"(xcc)::"memory");
+        unsigned long long *o = a.dbg + 24 * 128 + 3 * (size_t)blockIdx.x;
+        o[0] = blk_t0;
+        o[1] = blk_t1;
+        o[2] = ((unsigned long long)xcc << 32) | hwid;
     }
-    for (; t < t_hi; ++t) {
-        static_for<R>([&](auto jc) { row(jc, std::false_type{}, t); });
-        g3 ^= 1, g3n ^= 1;
-    }
-    for (; t < T_steps; ++t) {
-        static_for<R>([&](auto jc) { row(jc, std::true_type{}, t); });
-        g3 ^= 1, g3n ^= 1;
-    }
+#endif
+#ifdef QCNN_PH
+    if constexpr (!EXACT)
+        if (a.dbg && (int)blockIdx.x == a.dbg_block && lane == 0) {
+            for (int k = 0; k < 8; ++k) a.dbg[20 * 128 + k] = ph[k];
+            a.dbg[20 * 128 + 8] = ph_rows;
+        }
+#endif
 }
 
 hipError_t launch_fused_c3c4_stream2(const FusedArgs &a, bool exact, hipStream_t s)
@@ -422,8 +623,10 @@ hipError_t launch_fused_c3c4_stream2(const FusedArgs &a, bool exact, hipStream_t
     const long long units = (long long)a.nframes * nstrips * nseg;
     if (units > (1ll << 30)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((units + 7) / 8 * 8));  // a multiple of 8: see the unit map
-    if (exact) hipLaunchKernelGGL(k_c3c4s2<true>, grid, dim3(64), 0, s, a, nstrips, nseg, seg_rows, (int)units);
-    else hipLaunchKernelGGL(k_c3c4s2<false>, grid, dim3(64), 0, s, a, nstrips, nseg, seg_rows, (int)units);
+    // one round of waves: the workgroups past the first ncu * 4 / 8 of an XCD are the second ones on their SIMDs
+    const int second_from = (double)grid.x <= slots ? ncu * 4 / 8 : INT_MAX;
+    if (exact) hipLaunchKernelGGL(k_c3c4s2<true>, grid, dim3(64), 0, s, a, nstrips, nseg, seg_rows, (int)units, second_from);
+    else hipLaunchKernelGGL(k_c3c4s2<false>, grid, dim3(64), 0, s, a, nstrips, nseg, seg_rows, (int)units, second_from);
     return hipGetLastError();
 }
 
