@@ -363,6 +363,40 @@ __device__ __forceinline__ void mid_barrier()
 #endif
 }
 
+// Experiment (-DQCNN_A_FLAGS=1; measured slower, see below): hand-offs without a workgroup barrier, through two
+// counters in LDS that only grow.  produced = producer waves that have completed a tile (4 per tile), consumed =
+// consumer waves that have read a tile's last fragment (4 per consumer of a SIMD and tile).  A wave that waits polls
+// the word with a sleep between two reads; the bound on the number of polls only keeps a logic error from hanging
+// the device (it is never reached: tens of milliseconds).  Results are bit-identical; sustained on 512 frames the
+// kernel takes 70.6 us per frame against 68.2 with the barrier (2.11 M against 1.96 M cycles per 16 frames): the
+// older consumer of a SIMD runs a tile ahead and then waits for the producers, which wait for the younger one it
+// starves; with the younger one at priority 1 72.0, with neither consumer deferring its stores 69.4.
+#ifndef QCNN_A_FLAGS
+#define QCNN_A_FLAGS 0
+#endif
+#ifndef QCNN_A_FLAG_SLEEP
+#define QCNN_A_FLAG_SLEEP 1
+#endif
+__device__ __forceinline__ void flag_wait(const unsigned *flag, unsigned target, bool &alive)
+{
+    const unsigned addr = (unsigned)(size_t)flag;
+    if (!alive) return;  // (a wave that has given up once stops waiting: the launch ends, with garbage)
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        if ((int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) return;
+        __builtin_amdgcn_s_sleep(QCNN_A_FLAG_SLEEP);
+    }
+    alive = false;
+}
+// (every LDS access of this wave has completed before the counter moves)
+__device__ __forceinline__ void flag_signal(unsigned *flag, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+
 template <int PATH>
 __global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_waves_per_eu(A_WAVES / 4, A_WAVES / 4)))
 void k_c1c2(const FusedArgs a)
@@ -374,6 +408,7 @@ void k_c1c2(const FusedArgs a)
     // then all 43 C2 A fragments (loaded once per workgroup, read by every consumer tile)
     unsigned char *sYall = smem + 2 * SC1_BYTES;
     unsigned char *sW = smem + 2 * SC1_BYTES + 4 * SYW_BYTES;
+    unsigned *sProduced = reinterpret_cast<unsigned *>(smem + 2 * SC1_BYTES + 4 * SYW_BYTES + SW_BYTES), *sConsumed = sProduced + 1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -411,6 +446,12 @@ void k_c1c2(const FusedArgs a)
         v4i *dst = reinterpret_cast<v4i *>(sW);
         for (int i = tid; i < SW_BYTES / 16; i += A_THREADS) dst[i] = src[i];
     }
+#if QCNN_A_FLAGS
+    // the only workgroup barrier of the kernel: the weights and the zeroed counters are in LDS
+    if (tid < 2) sProduced[tid] = 0;
+    step_barrier();
+    bool alive = true;
+#endif
 
     // C2 constants of this lane, used by the consumer and by the producer's share of the C2 rows
     const int c = lane & 15, g = lane >> 4;
@@ -569,6 +610,13 @@ void k_c1c2(const FusedArgs a)
                 const int x0 = pos.tx * TW, y0 = pos.ty * TH;
                 const bool warm = n > 0 && pos.ty > 0;  // the tile above was this workgroup's previous tile
                 unsigned char *buf = smem + (n & 1) * SC1_BYTES;
+#if QCNN_A_FLAGS
+                static_assert(C2_CONS_ROWS == C2_BLOCK_ROWS, "the producers' share of the C2 rows is not handed off by counters");
+                // the tile above is complete (its last rows are copied), and every consumer has read the tile that
+                // sat in this buffer
+                if (warm) flag_wait(sProduced, 4u * n, alive);
+                if (n >= 2) flag_wait(sConsumed, 4u * C2_CONSUMERS * (n - 1), alive);
+#endif
                 if (pre_dwords) {
                     if (ylane4) {
                         const unsigned d0 = ypre4[0] ^ 0x80808080u, d1 = ypre4[1] ^ 0x80808080u, d2 = ypre4[2] ^ 0x80808080u;
@@ -694,13 +742,18 @@ void k_c1c2(const FusedArgs a)
 #if !C2_SHARE_FIRST
             c2_share(n);
 #endif
+#if QCNN_A_FLAGS
+            if (n < N) flag_signal(sProduced, lane);
+#endif
             if (n < N) {
                 prev = pos;
                 pos = nxt;
                 advance(nxt);
             }
             STAMP();
+#if !QCNN_A_FLAGS
             step_barrier();
+#endif
         }
     } else {
         // =============================== consumer ===============================
@@ -734,14 +787,23 @@ void k_c1c2(const FusedArgs a)
                     mid_barrier();
 #else
                     const unsigned char *buf = smem + ((n - 1) & 1) * SC1_BYTES;
+#if QCNN_A_FLAGS
+                    flag_wait(sProduced, 4u * n, alive);  // tile n-1 is complete
+#endif
                     if constexpr (DEFER) {
                         c2_mfma<EXACT, C2_ROWS, CONV>(acc, buf, R0c, cb, c, g, w22, w21, kc, store_then_release);
+#if QCNN_A_FLAGS
+                        flag_signal(sConsumed, lane);  // (the last fragment of the tile was read before its last MFMA)
+#endif
                         set_prio<C2_PRIO_D_VALU>();
                         held = pos;
                         have = true;
                     } else {
                         set_prio<C2_PRIO_N_MFMA>();
                         c2_mfma<EXACT, C2_ROWS, CONV>(acc, buf, R0c, cb, c, g, w22, w21, kc, [] { mid_barrier(); });
+#if QCNN_A_FLAGS
+                        flag_signal(sConsumed, lane);
+#endif
                         set_prio<C2_PRIO_N_VALU>();
                         c2_store<PATH, C2_ROWS, CONV>(acc, R0c, cb, c, g, kc, a.conc1 + QCNN_CONC_OFF(a, pos.f), pos.tx * TW,
                                                        pos.ty * TH, H, W);
@@ -752,7 +814,9 @@ void k_c1c2(const FusedArgs a)
                     mid_barrier();
                 }
                 STAMP();
+#if !QCNN_A_FLAGS
                 step_barrier();
+#endif
             }
             if constexpr (DEFER) store_held();
         };

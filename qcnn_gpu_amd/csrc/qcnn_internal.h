@@ -51,7 +51,8 @@ constexpr int YCOPY = ycopy_bytes(YWR * YWS);
 constexpr int SC1_BYTES = C1R * C1C * 64;
 constexpr int SYW_BYTES = 4 * YCOPY;
 constexpr int SW_BYTES = 43 * 1024;        // the 25 + 18 C2 A fragments
-constexpr int LDS_BYTES = 2 * SC1_BYTES + 4 * SYW_BYTES + SW_BYTES;
+constexpr int FLAG_BYTES = 16;             // hand-off counters of an experiment build of kernel A (unused otherwise)
+constexpr int LDS_BYTES = 2 * SC1_BYTES + 4 * SYW_BYTES + SW_BYTES + FLAG_BYTES;
 static_assert(SYW_BYTES % 16 == 0 && YWS % 4 == 0, "private Y tiles are read as aligned dwords");
 static_assert(LDS_BYTES <= 160 * 1024, "kernel A exceeds the 160 KiB of LDS of one CU");
 }  // namespace ka
