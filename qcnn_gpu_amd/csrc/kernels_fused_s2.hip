@@ -74,7 +74,11 @@ template <bool EXACT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_units, int second_from)
 {
+#ifdef QCNN_ABL_LONE  // diagnostic builds only: LDS for four workgroups per CU, i.e. a wave has its SIMD to itself
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WG_LDS];
+#else
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_LDS];
+#endif
     const int lane = threadIdx.x & 63;
     // Workgroups (single waves) are dealt to the 8 XCDs round robin; XCD x takes the x-th eighth of the units, so that
     // strips that share conc1 columns run on one XCD at about the same time and meet in its L2.
