@@ -439,6 +439,10 @@ void k_c1c2(const FusedArgs a)
         }
     };
     STAMP_INIT();
+#ifdef QCNN_STAMPS  // diagnostic builds only: when this workgroup started
+    unsigned long long blk_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t0)::"memory");
+#endif
 
     // C2 weights -> LDS, once.  They are first read after the barrier that ends step 0.
     {
@@ -845,6 +849,16 @@ void k_c1c2(const FusedArgs a)
 #endif
         }
     }
+#ifdef QCNN_STAMPS  // diagnostic builds only: start, end and tile count per wave 0 / 4 / 8 of every workgroup
+    if (a.dbg && lane == 0 && (wv == 0 || wv == 4 || wv == 8) && blockIdx.x < 2048) {
+        unsigned long long blk_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t1)::"memory");
+        unsigned long long *o = a.dbg + 24 * 128 + 3 * (size_t)(8192 + (wv >> 2) * 2048 + blockIdx.x);
+        o[0] = blk_t0;
+        o[1] = blk_t1;
+        o[2] = (unsigned long long)N;
+    }
+#endif
 }
 
 // mode: 0 integer epilogues, 1 float pipeline, 2 integer epilogues with clamped C2 accumulators
