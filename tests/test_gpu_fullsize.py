@@ -229,3 +229,37 @@ def test_driver_streaming_500_frames_of_1080p_bounded_host_memory(tmp_path):
         assert np.array_equal(rec[i, :hw].reshape(h, w), rec_o), f"frame {i}"
         assert not rec[i, hw:].any()                                # chroma bytes are zeros (inference/yuv_data.cpp:119-125)
         assert ("PSNR of Frame %d:%f\n" % (i, c_oracle.psnr(rec_o, np.ascontiguousarray(o)))) in r.stdout
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seg_rows,exact", [(None, 0), ("24", 0), ("270", 0), (None, 1)])
+def test_kernel_b_launch_shapes_on_16_whole_1080p_frames(seg_rows, exact, monkeypatch):
+    """Kernel B's launch of 16 x 1080p frames in the shapes its scheduling distinguishes: its own choice (one round of
+    2048 single-wave workgroups, two per SIMD, the second of which alternates its priority), bands of 24 rows (46 080
+    workgroups: many rounds, no priority changes), bands of 270 rows (two rounds), and the float path; every frame
+    distinct, every frame compared whole with the oracle (strips at the frame edges run their own form of the row)."""
+    h, w, qp, nf = 1080, 1920, 37, 16
+    if seg_rows:
+        monkeypatch.setenv("QCNN_SEG_ROWS", seg_rows)
+    if exact:
+        monkeypatch.setenv("QCNN_FORCE_EXACT", "1")
+    _, anc = _distinct_clip(h, w, qp, nf)
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    import ctypes as C
+    lib = capi.load()
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        d_in, d_out = C.c_void_p(), C.c_void_p()
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_in), nf * h * w))
+        capi.check(lib.qcnn_dev_alloc(C.byref(d_out), nf * h * w))
+        try:
+            capi.check(lib.qcnn_dev_h2d(d_in, anc.ctypes.data, nf * h * w))
+            net.forward_blu_batch(d_in.value, d_out.value, nf, h * w)
+            net.synchronize()
+            out = np.empty((nf, h, w), np.uint8)
+            capi.check(lib.qcnn_dev_d2h(out.ctypes.data, d_out, nf * h * w))
+        finally:
+            lib.qcnn_dev_free(d_in)
+            lib.qcnn_dev_free(d_out)
+    for i in range(nf):
+        assert np.array_equal(out[i], c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i]))), f"frame {i} differs from the oracle"
