@@ -919,9 +919,22 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
         }                                                                                      \
     } while (0)
     if (sse) HIP_TRY_C(hipMemsetAsync(d_sse, 0, 2 * (size_t)nframes * sizeof(unsigned long long), e->stream));
-    for (int k = 0, i0 = 0; i0 < nframes; ++k, i0 += chunk) {
+    // Chunk sizes: a long clip starts and ends with chunks of an eighth, a quarter and half a launch group, so that the
+    // kernels wait for the copy-in of two frames instead of sixteen at the start and the caller for the copy-out of
+    // two at the end.
+    std::vector<int> sizes;
+    {
+        int head[3] = {chunk / 8, chunk / 4, chunk / 2}, left = nframes;
+        const bool ramp = chunk >= 8 && nframes >= 4 * chunk && !getenv("QCNN_CLIP_NO_RAMP");
+        if (ramp)
+            for (int i = 0; i < 3; ++i) sizes.push_back(head[i]), left -= 2 * head[i];
+        for (; left > 0; left -= chunk) sizes.push_back(left < chunk ? left : chunk);
+        if (ramp)
+            for (int i = 2; i >= 0; --i) sizes.push_back(head[i]);
+    }
+    for (int k = 0, i0 = 0; k < (int)sizes.size(); i0 += sizes[k], ++k) {
         const int b = k & 1;
-        const int nf = nframes - i0 < chunk ? nframes - i0 : chunk;
+        const int nf = sizes[k];
         // copy-in stream: slot b is free once the kernels of chunk k-2 have read it
         HIP_TRY_C(hipStreamWaitEvent(e->s_in, e->ev_comp[b], 0));
         HIP_TRY_C(hipMemcpy2DAsync(e->ring_in[b], HW, host_y + (size_t)i0 * stride, stride, HW, nf, hipMemcpyHostToDevice,

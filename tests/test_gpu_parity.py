@@ -4,6 +4,7 @@ Tolerance: none.  Every comparison below is np.array_equal on bytes (uint8 / int
 bit patterns of integer-valued accumulators.
 """
 import ctypes as C
+import os
 import zlib
 
 import numpy as np
@@ -337,6 +338,33 @@ def test_host_clip_pipeline(group):
         net.batch_group(group)
         rec, before, after = net.forward_blu_clip(anc, ori)
         rec2 = net.forward_blu_clip(anc)
+    assert np.array_equal(rec, rec2)
+    for i in range(nf):
+        rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i]))
+        assert np.array_equal(rec[i], rec_o), f"frame {i}"
+        assert int(before[i]) == c_oracle.sse(np.ascontiguousarray(anc[i]), np.ascontiguousarray(ori[i]))
+        assert int(after[i]) == c_oracle.sse(rec_o, np.ascontiguousarray(ori[i]))
+
+
+@pytest.mark.parametrize("group,nf", [(16, 64), (16, 77), (8, 33)])
+def test_host_clip_pipeline_ramped_chunks(group, nf):
+    """A clip of at least four launch groups starts and ends with chunks of group/8, group/4 and group/2 frames
+    (64 frames in groups of 16: 2 4 8 16 16 4 8 4 2 ...): every frame and both SSE sums against the oracle, and the
+    same bytes with the ramp switched off."""
+    qp, h, w = 32, 23, 45
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    ori_b, anc_b = synth.synth_frames(h, w, qp, frames=8, seed=11)
+    ori = np.stack([np.roll(ori_b[i % 8], (3 * i, 5 * i), (0, 1)) for i in range(nf)])
+    anc = np.stack([np.roll(anc_b[i % 8], (3 * i, 5 * i), (0, 1)) for i in range(nf)])
+    with qvrcnn(0, 1, 1, h, w) as net:
+        net.load_static_para(mb)
+        net.batch_group(group)
+        rec, before, after = net.forward_blu_clip(anc, ori)
+        os.environ["QCNN_CLIP_NO_RAMP"] = "1"
+        try:
+            rec2 = net.forward_blu_clip(anc)
+        finally:
+            del os.environ["QCNN_CLIP_NO_RAMP"]
     assert np.array_equal(rec, rec2)
     for i in range(nf):
         rec_o = c_oracle.forward_blu(mb, np.ascontiguousarray(anc[i]))
