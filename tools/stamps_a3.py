@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: how long each of kernel A's workgroups runs in a launch of 16 frames (-DQCNN_STAMPS build, light:
--DQCNN_STAMPS_NOPH has no meaning for kernel A, its per-step stamps stay on), per role wave 0 (producer), 4 (older
-consumer), 8 (younger consumer), with the tile count of the workgroup."""
+"""Diagnostic: how long each of kernel A's workgroups runs in a launch of 16 frames (-DQCNN_STAMPS build; STAMPS_LIB
+names the build directory), per role -- wave 0 (producer), 4 (older consumer), 8 (younger consumer) -- with the tile
+count of the workgroup."""
 import ctypes as C
 import os
 import sys

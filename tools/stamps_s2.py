@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""Diagnostic: runs a -DQCNN_STAMPS -DQCNN_B_FINE build on a batch of 1080p frames and prints the cycles one wave of
-kernel B (two-tile form) spends per phase of a row, averaged over the rows of its fast loop.
-Phases: 0 top-of-row wait, 1 C4 MFMAs + LDS reads + third kernel row, 2 gathers + second kernel row, 3 first kernel
-row, 4 C3_2 + C3_1 requantiser, 5 output + stores, 6 row requests, 7 loop overhead between rows."""
+"""Diagnostic: runs a -DQCNN_STAMPS build (make -C qcnn_gpu_amd/csrc variant NAME=lib_stamps ALT=-DQCNN_STAMPS;
+STAMPS_LIB names the build directory) on a batch of 1080p frames and prints
+  * the ticks one wave of kernel B (two-tile form, QCNN_STAMP_BLOCK picks the workgroup) spends per phase of a row,
+    averaged over its untested rows -- 0 top-of-row wait, 1 C4 MFMAs + LDS reads + third kernel row, 2 gathers +
+    second kernel row, 3 first kernel row, 4 C3_2 + end of the requantiser, 5 stores, 6 row requests, 7 between rows
+    (not with -DQCNN_STAMPS_NOPH, which leaves the rows alone and stamps only the start and end of every workgroup);
+  * when and where every workgroup of the last launch ran: residency per compute unit, the distribution of the
+    workgroups' durations, by frame, strip, band, XCD and SIMD, and whether the two waves of a SIMD take equally long."""
 import ctypes as C
 import os
 import sys
@@ -72,8 +76,6 @@ print("peak resident workgroups per compute unit: min %d median %d max %d" % (pe
 dur = (t1 - t0)
 q = np.percentile(dur, [0, 5, 25, 50, 75, 95, 100])
 print("duration ticks: min %d p5 %d p25 %d median %d p75 %d p95 %d max %d" % tuple(q))
-nb = 16384
-ids = np.nonzero(np.zeros(1) == 0)[0]  # placeholder
 allblk = np.zeros((16384, 3), np.uint64)
 lib.qcnn_debug_blocks(net._h, allblk.ctypes.data_as(C.c_void_p))
 valid = np.nonzero(allblk[:, 1] > 0)[0]
