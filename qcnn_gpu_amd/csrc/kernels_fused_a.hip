@@ -397,9 +397,15 @@ __device__ __forceinline__ void flag_signal(unsigned *flag, int lane)
     asm volatile("" ::: "memory");
 }
 
+// Runs of tiles of the workgroups of one launch: workgroup b walks tiles start[b] .. start[b + 1] - 1.
+constexpr int A_MAX_GROUPS = 320;
+struct TileRuns {
+    int start[A_MAX_GROUPS + 1];
+};
+
 template <int PATH>
 __global__ __launch_bounds__(A_THREADS) __attribute__((amdgpu_waves_per_eu(A_WAVES / 4, A_WAVES / 4)))
-void k_c1c2(const FusedArgs a)
+void k_c1c2(const FusedArgs a, const TileRuns runs)
 {
     using namespace ka;
     constexpr bool EXACT = PATH == A_FLOAT;
@@ -417,13 +423,11 @@ void k_c1c2(const FusedArgs a)
     const int tiles_x = (W + TW - 1) / TW;
     const int tpf = tiles_x * ((H + TH - 1) / TH);  // tiles per frame
     const int ntiles = tpf * a.nframes;
-    const int first = blockIdx.x, stride = gridDim.x;
     // tiles in column-major order (frame, tile column, tile row); workgroup b takes the contiguous run
-    // [b * chunk, (b + 1) * chunk) of that order
+    // [start[b], start[b + 1]) of that order (the launcher cuts the runs to equal cost, not to equal length)
     const int tiles_y = (H + TH - 1) / TH;
-    const int chunk = (ntiles + stride - 1) / stride;
-    const int k0 = first * chunk;
-    const int N = k0 < ntiles ? (ntiles - k0 < chunk ? ntiles - k0 : chunk) : 0;  // tiles of this workgroup
+    const int k0 = runs.start[blockIdx.x];
+    const int N = runs.start[blockIdx.x + 1] - k0;  // tiles of this workgroup
     TilePos pos;  // the tile the role below handles next
     pos.f = k0 / tpf;
     pos.tx = (k0 - pos.f * tpf) / tiles_y;
@@ -866,11 +870,42 @@ hipError_t launch_fused_c1c2(const FusedArgs &a, int mode, hipStream_t s)
 {
     const int ntiles = ((a.W + ka::TW - 1) / ka::TW) * ((a.H + ka::TH - 1) / ka::TH) * a.nframes;
     if (ntiles < 1) return hipSuccess;
-    const int ncu = a.ncu > 0 ? a.ncu : 256;
-    dim3 grid(ntiles < ncu ? ntiles : ncu);
-    if (mode == A_FLOAT) hipLaunchKernelGGL(k_c1c2<A_FLOAT>, grid, dim3(A_THREADS), 0, s, a);
-    else if (mode == A_WIDE) hipLaunchKernelGGL(k_c1c2<A_WIDE>, grid, dim3(A_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_c1c2<A_INT>, grid, dim3(A_THREADS), 0, s, a);
+    int ncu = a.ncu > 0 ? a.ncu : 256;
+    if (ncu > A_MAX_GROUPS) ncu = A_MAX_GROUPS;
+    const int groups = ntiles < ncu ? ntiles : ncu;
+    // One persistent workgroup per CU; the launch lasts as long as the workgroup with the most work.  A tile in the
+    // leftmost or rightmost tile column of a frame costs more than the others (all four producers stage its Y pixels
+    // byte by byte with clamped addresses): 1.042 times as much, from a least-squares fit of the workgroups' durations
+    // on their tile counts by kind (tools/stamps_a3.py).  The runs are cut at equal cost: with runs of equal length
+    // the workgroups that hold two such columns ended 2.4 % after the median one.
+    const int tiles_x = (a.W + ka::TW - 1) / ka::TW, tiles_y = (a.H + ka::TH - 1) / ka::TH;
+    const double edge_cost = getenv("QCNN_A_EQUAL_RUNS") ? 1.0 : 1.042;
+    TileRuns runs;
+    {
+        const long long columns = (long long)tiles_x * a.nframes;
+        auto column_cost = [&](long long col) {
+            const int tx = (int)(col % tiles_x);
+            return (tx == 0 || tx == tiles_x - 1) ? edge_cost : 1.0;
+        };
+        double total = 0;
+        for (long long c = 0; c < columns; ++c) total += column_cost(c) * tiles_y;
+        long long col = 0;
+        double before = 0;  // cost of the columns in front of `col`
+        runs.start[0] = 0;
+        for (int b = 1; b < groups; ++b) {
+            const double target = total * b / groups;
+            while (col < columns && before + column_cost(col) * tiles_y <= target) before += column_cost(col++) * tiles_y;
+            long long k = col * tiles_y + (col < columns ? (long long)((target - before) / column_cost(col) + 0.5) : 0);
+            if (k < runs.start[b - 1] + 1) k = runs.start[b - 1] + 1;  // (every workgroup gets a tile: groups <= ntiles)
+            if (k > ntiles - (groups - b)) k = ntiles - (groups - b);
+            runs.start[b] = (int)k;
+        }
+        runs.start[groups] = ntiles;
+    }
+    dim3 grid(groups);
+    if (mode == A_FLOAT) hipLaunchKernelGGL(k_c1c2<A_FLOAT>, grid, dim3(A_THREADS), 0, s, a, runs);
+    else if (mode == A_WIDE) hipLaunchKernelGGL(k_c1c2<A_WIDE>, grid, dim3(A_THREADS), 0, s, a, runs);
+    else hipLaunchKernelGGL(k_c1c2<A_INT>, grid, dim3(A_THREADS), 0, s, a, runs);
     return hipGetLastError();
 }
 

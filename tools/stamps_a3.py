@@ -45,3 +45,35 @@ for role, name in ((0, "producer 0"), (1, "older consumer 4"), (2, "younger cons
         print("   slowest workgroups:", [(int(i), int(d[i])) for i in order[-6:]], " fastest:", [(int(i), int(d[i])) for i in order[:4]])
         per_tile = d / np.maximum(n, 1)
         print("   ticks per tile: min %d median %d max %d" % (per_tile.min(), np.median(per_tile), per_tile.max()))
+
+# cost of a tile by kind, from the workgroups' durations: least squares over the workgroups of
+#   duration = c_int * interior + c_edge * (tiles on the left / right frame edge) + c_tb * (top / bottom tiles of inner columns)
+TH, TW = 20, 32
+tiles_x, tiles_y = (w + TW - 1) // TW, (h + TH - 1) // TH
+tpf = tiles_x * tiles_y
+ntiles = tpf * nf
+chunk = (ntiles + 255) // 256
+r = blk[8192: 8192 + 256]
+rows, ys = [], []
+for b in range(256):
+    k0 = b * chunk
+    n = max(0, min(chunk, ntiles - k0))
+    if n == 0 or r[b, 1] == 0:
+        continue
+    kinds = [0, 0, 0]
+    for k in range(k0, k0 + n):
+        t = k % tpf
+        tx, ty = t // tiles_y, t % tiles_y
+        if tx == 0 or tx == tiles_x - 1:
+            kinds[1] += 1
+        elif ty == 0 or ty == tiles_y - 1:
+            kinds[2] += 1
+        else:
+            kinds[0] += 1
+    rows.append(kinds + [1])
+    ys.append(int(r[b, 1] - r[b, 0]))
+A = np.array(rows, float)
+sol, *_ = np.linalg.lstsq(A, np.array(ys, float), rcond=None)
+print("ticks per tile: interior %.0f, left/right edge %.0f, top/bottom %.0f, per workgroup %.0f" % tuple(sol))
+pred = A @ sol
+print("fit residual: rms %.0f ticks of %.0f" % (np.sqrt(np.mean((pred - ys) ** 2)), np.mean(ys)))
