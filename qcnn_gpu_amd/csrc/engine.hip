@@ -600,7 +600,10 @@ int qcnn_create(int gpu, int batch, int channel, int height, int width, qcnn_t *
     e->conc_frames = 1;
     {
         // frames per launch of the batch entry point: up to 16, as many as fit a scratch budget of 8 GiB (of the
-        // device's 288: sixteen 3840 x 2160 frames take 6.4 GB of conc1 and run 1.8 % faster than five)
+        // device's 288: sixteen 3840 x 2160 frames take 6.4 GB of conc1 and run 1.8 % faster than five).  Longer
+        // launches were measured on 1080p frames (QCNN_BATCH_GROUP=32 / 64, kernel B still in launches of 16, see
+        // launch_frames): kernel A gains 0.9 % at 64 frames, kernel B loses 6 % when its launches no longer follow
+        // the kernel A launch of their own frames, the whole pass loses 0.6 %.
         const char *gb = getenv("QCNN_BATCH_GROUP");
         const long long fit = (8ll << 30) / (long long)conc_bytes(height, width);
         e->group = gb ? atoi(gb) : (int)(fit < 1 ? 1 : fit > 16 ? 16 : fit);
@@ -766,9 +769,20 @@ static int launch_frames(qcnn_engine *e, const uint8_t *y, uint8_t *rec, int nfr
     if (ev) HIP_TRY(hipEventRecord(ev[0], e->stream));
     HIP_TRY(launch_fused_c1c2(a, e->path_a, e->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], e->stream));
-    if (e->tiled_b) HIP_TRY(launch_fused_c3c4(a, e->path_b == PATH_FLOAT, e->stream));
-    else if (e->wide_b) HIP_TRY(launch_fused_c3c4_stream2(a, e->path_b == PATH_FLOAT, e->stream));
-    else HIP_TRY(launch_fused_c3c4_stream(a, e->path_b == PATH_FLOAT, e->stream));
+    // Kernel B in launches of at most 16 frames (only a group above the default of 16 is split): sixteen 1080p frames
+    // are one round of its waves, which is the shape it balances (two waves per SIMD that finish together); launches
+    // of several rounds measured 3.5 % (32 frames) and 10 % (64 frames) slower per frame.
+    constexpr int B_FRAMES = 16;
+    for (int i = 0; i < nframes; i += B_FRAMES) {
+        FusedArgs b = a;
+        b.nframes = nframes - i < B_FRAMES ? nframes - i : B_FRAMES;
+        b.y = a.y + (size_t)i * a.frame_stride;
+        b.rec = a.rec + (size_t)i * a.frame_stride;
+        b.conc1 = a.conc1 + (size_t)i * a.conc_stride;
+        if (e->tiled_b) HIP_TRY(launch_fused_c3c4(b, e->path_b == PATH_FLOAT, e->stream));
+        else if (e->wide_b) HIP_TRY(launch_fused_c3c4_stream2(b, e->path_b == PATH_FLOAT, e->stream));
+        else HIP_TRY(launch_fused_c3c4_stream(b, e->path_b == PATH_FLOAT, e->stream));
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[2], e->stream));
     return QCNN_OK;
 }
@@ -885,7 +899,8 @@ int qcnn_clip_reserve(qcnn_t *e, int nframes, int with_sse)
 {
     if (!e) return fail(QCNN_E_ARG, "null engine");
     if (nframes < 1) return QCNN_OK;
-    const int chunk = nframes < e->group ? nframes : e->group;
+    const int cg = e->group < 16 ? e->group : 16;  // the clip pipeline's chunk: see qcnn_forward_blu_clip
+    const int chunk = nframes < cg ? nframes : cg;
     int rc = ensure_clip(e, chunk, with_sse != 0, with_sse ? nframes : 0);
     return rc ? rc : ensure_conc(e, chunk);
 }
@@ -899,7 +914,10 @@ int qcnn_forward_blu_clip(qcnn_t *e, const uint8_t *host_y, uint8_t *host_rec, i
     if ((sse_before || sse_after) && !host_ori) return fail(QCNN_E_ARG, "SSE output without the original frames");
     if (nframes == 0) return QCNN_OK;
     const size_t HW = e->HW;
-    const int chunk = nframes < e->group ? nframes : e->group;
+    // chunks of at most 16 frames whatever the batch entry point's group: the pipeline's fill, drain and ring
+    // buffers grow with the chunk
+    const int cg = e->group < 16 ? e->group : 16;
+    const int chunk = nframes < cg ? nframes : cg;
     const bool sse = host_ori && (sse_before || sse_after);
     int rc = ensure_clip(e, chunk, sse, sse ? nframes : 0);
     if (rc) return rc;
