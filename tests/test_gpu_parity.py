@@ -296,6 +296,38 @@ def test_batch_of_frames_any_group(group):
     capi.check(lib.qcnn_dev_free(d_out))
 
 
+@pytest.mark.parametrize("form", ["two_tiles", "one_tile", "tiled"])
+def test_batch_group_above_sixteen_frames(form, monkeypatch):
+    """A launch group above 16 frames (qcnn_batch_group / QCNN_BATCH_GROUP): kernel A walks all 37 distinct frames in
+    one launch, kernel B the same frames in launches of 16, 16 and 5, in every form of kernel B."""
+    if form == "tiled":
+        monkeypatch.setenv("QCNN_B_TILED", "1")
+    elif form == "one_tile":
+        monkeypatch.setenv("QCNN_B_WIDE", "0")
+    qp, h, w, nf = 32, 31, 47, 37
+    mb = synth.synth_model(qp).to_nchw_vect_c_bytes()
+    base = synth.synth_frames(h, w, qp, frames=8, seed=123)[1]
+    frames = np.stack([np.roll(base[i % 8], (2 * i, 3 * i), (0, 1)) for i in range(nf)])
+    lib = capi.load()
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    capi.check(lib.qcnn_dev_alloc(C.byref(d_in), nf * h * w))
+    capi.check(lib.qcnn_dev_alloc(C.byref(d_out), nf * h * w))
+    try:
+        capi.check(lib.qcnn_dev_h2d(d_in, np.ascontiguousarray(frames).ctypes.data, nf * h * w))
+        with qvrcnn(0, 1, 1, h, w) as net:
+            net.load_static_para(mb)
+            assert net.batch_group(40) == 40
+            net.forward_blu_batch(d_in.value, d_out.value, nf, h * w)
+            net.synchronize()
+            out = np.empty((nf, h, w), np.uint8)
+            capi.check(lib.qcnn_dev_d2h(out.ctypes.data, d_out, nf * h * w))
+    finally:
+        lib.qcnn_dev_free(d_in)
+        lib.qcnn_dev_free(d_out)
+    for i in range(nf):
+        assert np.array_equal(out[i], c_oracle.forward_blu(mb, np.ascontiguousarray(frames[i]))), f"frame {i}"
+
+
 def test_batch_calls_back_to_back():
     """Batch calls of several groups each, queued back to back on two pairs of buffers without a synchronisation
     in between: every call reuses the conc1 image of the one before it."""
