@@ -34,83 +34,104 @@ BLU_INIT = {
 }
 
 
-def mul_shift(max_u: float) -> Tuple[int, int]:
-    """(mul, shift) with max_u * mul / 2**shift in (127, 127.5): the requantiser that maps the clip
-    threshold to 127 (training/quantization.py:5-14).  Falls through to shift 27 like the reference."""
+def _first_fitting_shift(target: float, shifts: range, top_of, fits) -> Tuple[int, int]:
+    """Walks the shifts upwards; for every shift whose numerator top_of(shift) exceeds `target` the multiplier is
+    round(top / target), and the first (mul, shift) that `fits` is returned.  When none fits, the last multiplier
+    tried goes with the largest shift (what the reference's loops leave behind when they fall through)."""
     mul = 0
-    shift = 27
-    for i in range(1, 28):
-        top = 127.5 * 2 ** i
-        if top > max_u:
-            mul = round(top / max_u)
-            got = max_u * mul / 2 ** i
-            if 127 < got < 127.5:
-                return mul, i
-    return mul, shift
+    for shift in shifts:
+        top = top_of(shift)
+        if top > target:
+            mul = round(top / target)
+            if fits(top, mul, shift):
+                return mul, shift
+    return mul, shifts[-1]
+
+
+def mul_shift(max_u: float) -> Tuple[int, int]:
+    """(mul, shift) with max_u * mul / 2**shift in (127, 127.5): the requantiser that maps the clip threshold to 127
+    (training/quantization.py:5-14)."""
+    return _first_fitting_shift(max_u, range(1, 28), lambda k: 127.5 * 2 ** k, lambda top, mul, k: 127 < max_u * mul / 2 ** k < 127.5)
 
 
 def mul_shift_f(ratio: float) -> Tuple[int, int]:
-    """(mul, shift) with 2**shift / mul within 2 % of `ratio`, shift >= 10: the residual scaler of the
-    last layer (training/quantization.py:15-24)."""
-    mul = 0
-    shift = 27
-    for i in range(10, 28):
-        top = 2 ** i
-        if top > ratio:
-            mul = round(top / ratio)
-            if abs(top / mul - ratio) < 0.02 * ratio:
-                return mul, i
-    return mul, shift
+    """(mul, shift) with 2**shift / mul within 2 % of `ratio`, shift >= 10: the residual scaler of the last layer
+    (training/quantization.py:15-24)."""
+    return _first_fitting_shift(ratio, range(10, 28), lambda k: 2 ** k, lambda top, mul, k: abs(top / mul - ratio) < 0.02 * ratio)
+
+
+# A row is [stepw, ratio, blu_adj, blu_q, mul, shift]; the helpers below name its fields.
+_STEPW, _RATIO, _BLU_ADJ, _BLU_Q, _MUL, _SHIFT = range(6)
+
+
+def _threshold_in_units(blu: float, ratio: float, stepw: float) -> int:
+    """The float clip threshold in integer units of the layer's accumulator."""
+    return round(blu * ratio / stepw)
+
+
+def _threshold_applied(mul: int, shift: int, stepw: float, ratio: float) -> float:
+    """The float threshold the integer clip really applies: the accumulator value that (mul, shift) map to 127."""
+    return 127 * 2 ** shift / mul * stepw / ratio
+
+
+def _gain(mul: int, shift: int, stepw: float) -> float:
+    """Output units per float unit and unit of ratio of a requantiser working on weights of step stepw."""
+    return mul / stepw / 2 ** shift
+
+
+def _ratio_behind(ratio: float, row: Row) -> float:
+    """Integer units per float unit of the activations behind a requantised layer."""
+    return ratio / row[_STEPW] * row[_MUL] / 2 ** row[_SHIFT]
 
 
 def quant_qfp_layer(ratio: float, stepw: float, blu: float) -> Row:
-    """A layer with its own threshold (C1): training/quantization.py:25-31."""
-    blu_q = round(blu * ratio / stepw)
-    mul, shift = mul_shift(blu_q)
-    blu_adj = 127 * 2 ** shift / mul * stepw / ratio  # the threshold the integer clip really applies
-    blu_q = round(blu_adj * ratio / stepw)
-    return [stepw, ratio, blu_adj, blu_q, mul, shift]
+    """A layer with its own threshold (C1): the requantiser is fitted to the threshold, then the threshold is moved
+    to where that requantiser clips (training/quantization.py:25-31)."""
+    mul, shift = mul_shift(_threshold_in_units(blu, ratio, stepw))
+    blu_adj = _threshold_applied(mul, shift, stepw, ratio)
+    return [stepw, ratio, blu_adj, _threshold_in_units(blu_adj, ratio, stepw), mul, shift]
 
 
 def quant_qfp_concat(ratio: float, stepw1: float, blu1: float, stepw2: float, blu2: float) -> List[Row]:
-    """Two branches that are concatenated must leave the requantiser on the same scale: the larger
-    threshold is used for both and the finer weight step is coarsened until
-    mul1 / stepw1 / 2**shift1 == mul2 / stepw2 / 2**shift2 (training/quantization.py:32-49)."""
-    blu1 = blu2 = max(blu1, blu2)
-    blu_q1 = round(blu1 * ratio / stepw1)
-    blu_q2 = round(blu2 * ratio / stepw2)
-    mul1, shift1 = mul_shift(blu_q1)
-    mul2, shift2 = mul_shift(blu_q2)
-    if mul1 / stepw1 / 2 ** shift1 > mul2 / stepw2 / 2 ** shift2:
+    """Two branches that are concatenated must leave their requantisers on the same scale: both take the larger
+    threshold, and the weight step of the branch with the larger gain is coarsened until the gains
+    mul / stepw / 2**shift are equal (training/quantization.py:32-49)."""
+    blu = max(blu1, blu2)
+    units = (_threshold_in_units(blu, ratio, stepw1), _threshold_in_units(blu, ratio, stepw2))
+    (mul1, shift1), (mul2, shift2) = mul_shift(units[0]), mul_shift(units[1])
+    if _gain(mul1, shift1, stepw1) > _gain(mul2, shift2, stepw2):
         stepw1 = stepw2 * 2 ** shift2 / mul2 * mul1 / 2 ** shift1
     else:
         stepw2 = stepw1 * 2 ** shift1 / mul1 * mul2 / 2 ** shift2
-    blu1_adj = 127 * 2 ** shift1 / mul1 * stepw1 / ratio
-    blu2_adj = 127 * 2 ** shift2 / mul2 * stepw2 / ratio
-    return [[stepw1, ratio, blu1_adj, blu_q1, mul1, shift1], [stepw2, ratio, blu2_adj, blu_q2, mul2, shift2]]
+    return [[stepw1, ratio, _threshold_applied(mul1, shift1, stepw1, ratio), units[0], mul1, shift1],
+            [stepw2, ratio, _threshold_applied(mul2, shift2, stepw2, ratio), units[1], mul2, shift2]]
 
 
 def quant_qfp_last(ratio: float, stepw: float) -> Row:
     """The residual layer C4: its output is brought back to the 8-bit pixel scale (ratio 255) by
-    (x * mul + round) >> shift in applyRes_y (training/quantization.py:50-53)."""
+    (x * mul + round) >> shift in applyRes_y; the weight step is moved to where that scaler is exact
+    (training/quantization.py:50-53)."""
     mul, shift = mul_shift_f(ratio / 255 / stepw)
-    stepw_adj = ratio * mul / 2 ** shift / 255
-    return [stepw_adj, ratio, 0, 0, mul, shift]
+    return [ratio * mul / 2 ** shift / 255, ratio, 0, 0, mul, shift]
 
 
 def adjust_quant(stepw_in: Sequence[float], blu_in: Sequence[float]) -> List[Row]:
-    """Rows of the six layers C1, C2_1, C2_2, C3_1, C3_2, C4 from the weight steps and the float clip
-    thresholds; `ratio` (integer units per float unit of the activations) is chained through the
-    requantisers (training/quantization.py:55-64)."""
+    """Rows of the six layers C1, C2_1, C2_2, C3_1, C3_2, C4 from the weight steps and the float clip thresholds.
+    `ratio` (integer units per float unit of the activations, 255 for the input pixels) is chained through the
+    requantisers: behind a concatenation both branches have the same ratio, the first one's is taken
+    (training/quantization.py:55-64)."""
+    rows: List[Row] = []
     ratio = 255
-    p1 = quant_qfp_layer(ratio, stepw_in[0], blu_in[0])
-    ratio = ratio / p1[0] * p1[4] / 2 ** p1[5]
-    p21, p22 = quant_qfp_concat(ratio, stepw_in[1], blu_in[1], stepw_in[2], blu_in[2])
-    ratio = ratio / p21[0] * p21[4] / 2 ** p21[5]
-    p31, p32 = quant_qfp_concat(ratio, stepw_in[3], blu_in[3], stepw_in[4], blu_in[4])
-    ratio = ratio / p31[0] * p31[4] / 2 ** p31[5]
-    p4 = quant_qfp_last(ratio, stepw_in[5])
-    return [p1, p21, p22, p31, p32, p4]
+    for stage in ((0,), (1, 2), (3, 4)):  # a single layer, then two pairs of concatenated branches
+        if len(stage) == 1:
+            new = [quant_qfp_layer(ratio, stepw_in[stage[0]], blu_in[stage[0]])]
+        else:
+            a, b = stage
+            new = quant_qfp_concat(ratio, stepw_in[a], blu_in[a], stepw_in[b], blu_in[b])
+        rows += new
+        ratio = _ratio_behind(ratio, new[0])
+    rows.append(quant_qfp_last(ratio, stepw_in[5]))
+    return rows
 
 
 def stepw_from_weights(weights: Sequence[np.ndarray]) -> List[float]:
