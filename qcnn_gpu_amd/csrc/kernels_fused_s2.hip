@@ -462,11 +462,18 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
         int yv[NT];
 #pragma unroll
         for (int T = 0; T < NT; ++T) yv[T] = *reinterpret_cast<const int *>(rdy[T] + j * YSLOT);
+#ifdef QCNN_ABL_FINE_NOBREAD  // diagnostic builds only (garbage results): no fragment reads
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) Bn[T][s] = B[T][s];
+#else
 #pragma unroll
         for (int T = 0; T < NT; ++T)
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 Bn[T][s] = *reinterpret_cast<const v4i *>((j + 1 < R ? rdc + (j + 1) * ROW_BYTES : rdo) + (16 * T + s) * 48);
+#endif
         SB();
         // third kernel row of conc2 row y2 (complete with it)
         acc[0][s2] = mfma16(f31[0][2], B[0][0], acc[0][s2]); SB(); RQ32(0, 0, 0); SB();
@@ -491,10 +498,18 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
         }
         {
             const int M0 = borrow ? P[1] : P[0];  // tile 0's gathers wrap into tile 1's first pixels
+#ifdef QCNN_ABL_FINE_NOBPERM  // diagnostic builds only (garbage results): no gathers
+            v1[0] = M0, v2[0] = M0 ^ addr1, v1[1] = P[1], v2[1] = P[1] ^ addr2;
+#else
+#ifdef QCNN_ABL_FINE_NOBPERM  // diagnostic builds only (garbage results): no gathers
+            v1[0] = M0, v2[0] = M0 ^ addr1, v1[1] = P[1], v2[1] = P[1] ^ addr2;
+#else
             v1[0] = __builtin_amdgcn_ds_bpermute(addr1, M0);
             v2[0] = __builtin_amdgcn_ds_bpermute(addr2, M0);
             v1[1] = __builtin_amdgcn_ds_bpermute(addr1, P[1]);
             v2[1] = __builtin_amdgcn_ds_bpermute(addr2, P[1]);
+#endif
+#endif
         }
         SB();
         const int y3 = y2 - 2;
@@ -526,7 +541,11 @@ void k_c3c4s2(const FusedArgs a, int nstrips, int nseg, int seg_rows, int total_
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
             const int voff = (!CHECK || (y3 >= ya && y3 < yb)) ? out_off[T] : OOB;
+#ifndef QCNN_ABL_FINE_NOSTORE  // (diagnostic builds leave the stores out: garbage results)
             asm volatile("buffer_store_byte %0, %1, %2, %3 offen" ::"v"(out[T]), "v"(voff), "s"(rec_rsrc), "s"(y3 * W) : "memory");
+#else
+            asm volatile("" ::"v"(out[T]), "v"(voff));
+#endif
         }
         PH(5);
         // then the requests for the slots this row has emptied (rows past the last one the band walks are not
